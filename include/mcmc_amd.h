@@ -1,0 +1,268 @@
+/*
+ * mcmc_amd.h -- C ABI of the MI355X (gfx950) batched MCMC engine.
+ *
+ * This is the drop-in boundary for the two sampling paths of slwu89/MCMC.  Every entry
+ * point cites the reference interface it replaces (paths are into the reference repo).
+ * Plain pointers and sizes only; no C++ or torch types.  The library is
+ * mcmc_amd/libmcmc_amd.so (hipcc --offload-arch=gfx950); INTEGRATION.md shows the
+ * Rcpp-side binding.
+ *
+ * Conventions
+ *   - "h_" arguments are HOST pointers, "d_" arguments are DEVICE (HBM) pointers on the
+ *     current HIP device.  The single-chain drop-in calls take host pointers only.
+ *   - Matrices handed over by the caller are column-major (R / Armadillo layout).
+ *   - Batch arrays are structure-of-arrays with the CHAIN index fastest:
+ *       state  [d][n_chains]              element (k, c)      at k*n_chains + c
+ *       trace  [n_kept][d][n_chains]      element (t, k, c)   at (t*d + k)*n_chains + c
+ *     so one wavefront (64 chains, or 64 consecutive lanes) writes 512 contiguous bytes.
+ *   - Every call returns MCMC_OK (0) or a negative MCMC_E_* code; mcmc_amd_last_error()
+ *     gives the message.  Per-chain failures (what would be a C++ exception inside the
+ *     reference's loop) are reported through the d_status / status outputs instead.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Batch calls
+ *     are asynchronous on that stream; the single-chain calls synchronise before returning.
+ *   - Random numbers: rng_mode MCMC_RNG_PHILOX draws from Philox4x32-10 keyed by `seed` and
+ *     counted by (global chain id, iteration, draw), so results do not depend on how chains
+ *     are split over launches or GPUs; MCMC_RNG_INJECTED consumes caller-supplied N(0,1) /
+ *     U(0,1) arrays in exactly the order the reference draws them (the parity mode).
+ */
+#ifndef MCMC_AMD_H
+#define MCMC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCMC_AMD_ABI_VERSION 1
+
+/* ----- return codes ---------------------------------------------------------------- */
+#define MCMC_OK 0
+#define MCMC_E_BAD_ARG (-1)       /* shape / range / NULL pointer problem, nothing launched   */
+#define MCMC_E_UNSUPPORTED (-2)   /* valid request this build has no kernel for               */
+#define MCMC_E_HIP (-3)           /* a HIP runtime call failed                                */
+#define MCMC_E_NOT_PD (-4)        /* a shared (host-side) matrix is not positive definite     */
+#define MCMC_E_CHAIN_FAILED (-5)  /* single-chain call: the chain stopped (see *fail_iter)    */
+
+/* ----- per-chain status word (d_status) -------------------------------------------- */
+/* 0 = ran to completion.  Otherwise (iteration << 4) | code, iteration 1-based.          */
+#define MCMC_CHAIN_OK 0
+#define MCMC_CHAIN_CHOL_FAILED 1      /* arma::chol would have thrown (adaptMCMC_source.cpp:153) */
+#define MCMC_CHAIN_NONFINITE_STATE 2  /* Gibbs draw became +-Inf/NaN (tmvrnormGibbs.cpp:132 has no tail handling) */
+#define MCMC_STATUS_CODE(s) ((s) & 15)
+#define MCMC_STATUS_ITER(s) ((s) >> 4)
+
+/* ----- random-number source --------------------------------------------------------- */
+#define MCMC_RNG_PHILOX 0
+#define MCMC_RNG_INJECTED 1
+
+/* ----- target log-densities --------------------------------------------------------- */
+/*
+ * Replaces the R closure `target` of adaptMCMC / rwMCMC (adaptMCMC_source.cpp:75,97,158;
+ * :230,246,277), which a GPU cannot call.  A target is a kind plus a host parameter block.
+ */
+#define MCMC_TARGET_GAUSSIAN_PREC 0   /* -0.5 (x-m)^T H (x-m); params = m[d], H[d*d] column-major */
+#define MCMC_TARGET_GOLDSTEIN_PRICE 1 /* adaptMCMC_analysis.R:115-129 (d = 2); no params          */
+#define MCMC_TARGET_BANANA 2          /* adaptMCMC_analysis.R:19-22  (d = 2); params = B          */
+
+typedef struct mcmc_target {
+    int32_t kind;
+    int32_t n_params;
+    const double *h_params;
+} mcmc_target;
+
+/* ----- library ----------------------------------------------------------------------- */
+int mcmc_amd_abi_version(void);
+const char *mcmc_amd_last_error(void);
+/* largest d served by the one-chain-per-lane kernels; above it the per-wavefront kernels run */
+int mcmc_amd_max_lane_dim(void);
+int mcmc_amd_max_dim(void);
+
+/* =====================================================================================
+ * Adaptive random-walk Metropolis, many chains
+ * replaces: List adaptMCMC(Function target, arma::vec init_theta, arma::mat covmat,
+ *   int n_iterations, int adapt_size_start, double acceptance_rate_weight,
+ *   int acceptance_window, int adapt_shape_start, int info, double seedMH,
+ *   double adapt_size_cooling = 0.99, double max_scaling_sd = 50.0)
+ *   (adaptMCMC_source.cpp:75-219), run once per chain; and rwMCMC (:230-316), which is the
+ *   same loop with adapt_size_start = adapt_shape_start = 0, weight = 0, window = 0.
+ * ===================================================================================== */
+typedef struct mcmc_rwm_config {
+    int32_t d;                     /* length of init_theta                                   */
+    int32_t n_iterations;
+    int64_t n_chains;              /* chains in THIS call                                    */
+    int64_t chain_offset;          /* global id of local chain 0 (Philox counter)            */
+    int32_t adapt_size_start;      /* 0 disables size adaptation  (:31,117)                  */
+    int32_t adapt_shape_start;     /* 0 disables shape adaptation (:31,131)                  */
+    int32_t acceptance_window;     /* 0 = off; 1..64 supported on the device                 */
+    int32_t thin;                  /* keep iteration i when i % thin == 0 (>= 1)             */
+    double acceptance_rate_weight;
+    double adapt_size_cooling;     /* reference default 0.99                                 */
+    double max_scaling_sd;         /* reference default 50.0                                 */
+    uint64_t seed;                 /* Philox key                                             */
+    int32_t rng_mode;              /* MCMC_RNG_PHILOX | MCMC_RNG_INJECTED                     */
+    int32_t reserved;
+} mcmc_rwm_config;
+
+typedef struct mcmc_rwm_io {
+    /* inputs */
+    const double *h_init_theta;    /* [d] start shared by all chains, used when d_init == NULL */
+    const double *d_init;          /* [d][n_chains] per-chain start, or NULL                 */
+    const double *h_covmat;        /* [d*d] column-major, shared (arma::mat covmat)          */
+    const double *d_Z;             /* INJECTED: [n_iterations][d][n_chains] normals, Y(k) of iteration i at ((i-1)*d+k)*n_chains+c (:149-152) */
+    const double *d_U;             /* INJECTED: [n_iterations][n_chains] uniforms A (:174)   */
+    /* outputs, each may be NULL */
+    double *d_trace;               /* theta_trace: [n_iterations/thin][d][n_chains] (:185)   */
+    double *d_sigma_trace;         /* sigma_empirical: [n_iterations/thin][d*d][n_chains], column-major d x d slices (:214) */
+    double *d_final_theta;         /* [d][n_chains]                                          */
+    double *d_final_mean;          /* theta_mean: [d][n_chains] (:212)                       */
+    double *d_final_cov;           /* covmat_empirical: [d*d][n_chains] column-major (:211)  */
+    double *d_acceptance_rate;     /* [n_chains] (:218)                                      */
+    int32_t *d_status;             /* [n_chains] per-chain status word                        */
+    /* parity diagnostics, each may be NULL: one value per iteration and chain, [n_iterations][n_chains] */
+    uint8_t *d_accepted;           /* is_accepted                                            */
+    double *d_log_acceptance;      /* log_acceptance after :168-170                           */
+    double *d_log_A;               /* log(A), :175                                           */
+    double *d_scaling_sd;          /* scaling_sd after the adaptation block :117-139          */
+    double *d_scaling_multiplier;  /* scaling_multiplier after the adaptation block (:123)    */
+    double *d_rate_trace;          /* acceptance_rate after :188-207                          */
+} mcmc_rwm_io;
+
+int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_config *cfg,
+                         const mcmc_rwm_io *io, void *stream);
+
+/* Fills the N(0,1) / U(0,1) arrays that mcmc_adapt_rwm_batch would draw in MCMC_RNG_PHILOX
+ * mode for the same (seed, chain_offset, n_chains, n_iterations, d), in the d_Z / d_U layout
+ * above.  Lets a checker replay a Philox run through the reference with identical streams.
+ * No counterpart in the reference (its RNG is std::mt19937, adaptMCMC_source.cpp:78-80). */
+int mcmc_rwm_streams(uint64_t seed, int64_t chain_offset, int64_t n_chains, int32_t n_iterations,
+                     int32_t d, double *d_Z, double *d_U, void *stream);
+
+/* Per-chain start points theta0[k][c] = mean[k] + sd * N(0,1) from Philox(seed) (stream tag
+ * "init"), layout [d][n_chains].  No counterpart in the reference (callers pass init_theta). */
+int mcmc_init_normal(uint64_t seed, int64_t chain_offset, int64_t n_chains, int32_t d,
+                     const double *h_mean, double sd, double *d_out, void *stream);
+
+/* ----- single chain, host pointers, reference layout (the Rcpp drop-in) ---------------
+ * replaces: adaptMCMC (adaptMCMC_source.cpp:75-219).
+ *   theta_trace      n_iterations x d, column-major                     (:92,185,218)
+ *   sigma_empirical  d x d x n_iterations (arma::cube) or NULL          (:93,214,218)
+ *   acceptance_rate  scalar                                              (:218)
+ *   h_Z / h_U        optional injected streams (Z[(i-1)*d+k], U[i-1]); both NULL = Philox
+ *                    keyed by seedMH (converted like std::mt19937's seed: to uint64, :78)
+ *   info             must be > 0 (the reference computes i % info, :142); info_log, if not
+ *                    NULL, receives for every i with i % info == 0 the three numbers the
+ *                    reference prints at :144 -- acceptance_rate, scaling_sd,
+ *                    scaling_multiplier -- as info_log[3*(i/info - 1) + 0..2]
+ *   fail_iter        0, or the 1-based iteration at which chol failed (then the call
+ *                    returns MCMC_E_CHAIN_FAILED; rows from that iteration on are NaN)
+ */
+int mcmc_adaptMCMC(const mcmc_target *target, int32_t d, const double *h_init_theta,
+                   const double *h_covmat, int32_t n_iterations, int32_t adapt_size_start,
+                   double acceptance_rate_weight, int32_t acceptance_window,
+                   int32_t adapt_shape_start, int32_t info, double seedMH,
+                   double adapt_size_cooling, double max_scaling_sd, const double *h_Z,
+                   const double *h_U, double *h_theta_trace, double *h_sigma_empirical,
+                   double *h_acceptance_rate, double *h_info_log, int32_t *fail_iter);
+
+/* replaces: List rwMCMC(Function target, arma::vec init_theta, arma::mat covmat,
+ *   int n_iterations, int info, double seedMH) (adaptMCMC_source.cpp:230-316);
+ *   returns theta_trace (n x d column-major) and acceptance_rate (:315). */
+int mcmc_rwMCMC(const mcmc_target *target, int32_t d, const double *h_init_theta,
+                const double *h_covmat, int32_t n_iterations, int32_t info, double seedMH,
+                const double *h_Z, const double *h_U, double *h_theta_trace,
+                double *h_acceptance_rate, int32_t *fail_iter);
+
+/* =====================================================================================
+ * Truncated multivariate normal Gibbs sampler, many chains
+ * replaces: arma::mat rtmvnorm_gibbs(int n, arma::vec mu, arma::mat sigma, arma::vec lower,
+ *   arma::vec upper, arma::vec init_state) (tmvrnormGibbs.cpp:91-142), run once per chain.
+ * ===================================================================================== */
+typedef struct mcmc_gibbs_config {
+    int32_t d;
+    int32_t n_sweeps;              /* the reference's n                                       */
+    int64_t n_chains;
+    int64_t chain_offset;
+    int32_t thin;                  /* keep sweep j (1-based) when j % thin == 0               */
+    int32_t burn;                  /* sweeps excluded from the running moments                */
+    uint64_t seed;
+    int32_t rng_mode;
+    int32_t tail_safe;             /* 0 = the reference formula (:130-132) verbatim;
+                                      1 = same draw computed from whichever tail keeps
+                                          precision (needed when a bound is > ~8 sd out,
+                                          where the reference returns +-Inf)                  */
+} mcmc_gibbs_config;
+
+typedef struct mcmc_gibbs_io {
+    const double *h_mu;            /* [d]                                                    */
+    const double *h_sigma;         /* [d*d] column-major covariance                           */
+    const double *h_lower;         /* [d], -INFINITY allowed                                  */
+    const double *h_upper;         /* [d], +INFINITY allowed                                  */
+    const double *h_init_state;    /* [d] shared start, used when d_init == NULL              */
+    const double *d_init;          /* [d][n_chains] or NULL                                   */
+    const double *d_U;             /* INJECTED: [n_sweeps][d][n_chains]; U(l), l = j*d+i, of chain c at (j*d+i)*n_chains+c (:97,132-133) */
+    double *d_trace;               /* [n_sweeps/thin][d][n_chains] or NULL (:137)             */
+    double *d_final_state;         /* [d][n_chains] or NULL                                   */
+    double *d_mean;                /* running mean  of x over sweeps > burn: [d][n_chains] or NULL */
+    double *d_m2;                  /* running sum of squared deviations (Welford M2): [d][n_chains] or NULL */
+    int32_t *d_status;             /* [n_chains] or NULL                                      */
+} mcmc_gibbs_io;
+
+int mcmc_tmvn_gibbs_batch(const mcmc_gibbs_config *cfg, const mcmc_gibbs_io *io, void *stream);
+
+/* The shared precompute of tmvrnormGibbs.cpp:100-113 (regression rows P_i and conditional
+ * sd_i), obtained from the precision matrix H = sigma^-1: P_i = -H[i,-i]/H_ii,
+ * sd_i = 1/sqrt(H_ii).  h_P is d rows of d-1 entries (row-major), h_sd is [d]. */
+int mcmc_tmvn_precompute(int32_t d, const double *h_sigma, double *h_P, double *h_sd);
+
+/* Fills the uniforms a MCMC_RNG_PHILOX Gibbs run would use, in the d_U layout above. */
+int mcmc_gibbs_streams(uint64_t seed, int64_t chain_offset, int64_t n_chains, int32_t n_sweeps,
+                       int32_t d, double *d_U, void *stream);
+
+/* single chain, host pointers, reference layout.
+ * replaces: rtmvnorm_gibbs (tmvrnormGibbs.cpp:91-142); h_trace is n x d column-major;
+ * h_U optional (n*d uniforms in the reference's order), NULL = Philox(seed). */
+int mcmc_rtmvnorm_gibbs(int32_t n, int32_t d, const double *h_mu, const double *h_sigma,
+                        const double *h_lower, const double *h_upper, const double *h_init_state,
+                        const double *h_U, uint64_t seed, double *h_trace);
+
+/* replaces: NumericVector rtnorm_gibbs(int n, double mu, double sigma, double a, double b)
+ * (tmvrnormGibbs.cpp:49-70); h_F optional (the runif(n) draws), NULL = Philox(seed). */
+int mcmc_rtnorm_gibbs(int32_t n, double mu, double sigma, double a, double b, const double *h_F,
+                      uint64_t seed, double *h_out);
+/* device-resident variant of the same draw: d_F may be NULL (Philox), d_out is [n]. */
+int mcmc_rtnorm_batch(int64_t n, double mu, double sigma, double a, double b, const double *d_F,
+                      uint64_t seed, int64_t offset, int32_t tail_safe, double *d_out, void *stream);
+
+/* Index-shedding helpers (host, column-major).
+ * replaces: sub1 (tmvrnormGibbs.cpp:12-16)  out = x[-i,-i], (d-1) x (d-1)
+ *           sub2 (:20-23)                    out = x[a,-b],  1 x (nc-1)
+ *           negSubCol (:27-30), negSubRow (:34-37)  out = x[-i]
+ * i, a, b are 0-based as in the reference.  On the device these vanish into indexing. */
+int mcmc_sub1(int32_t d, const double *h_x, int32_t i, double *h_out);
+int mcmc_sub2(int32_t nr, int32_t nc, const double *h_x, int32_t a, int32_t b, double *h_out);
+int mcmc_negSubCol(int32_t n, const double *h_x, int32_t i, double *h_out);
+int mcmc_negSubRow(int32_t n, const double *h_x, int32_t i, double *h_out);
+
+/* =====================================================================================
+ * Cross-chain diagnostics (no counterpart in the reference: coda is loaded at
+ * MCMCutilty.R:11 but never called).  The partial sums are what one RCCL all-reduce
+ * carries between GPUs.
+ * ===================================================================================== */
+/* Per-chain mean and unbiased variance over kept draws t >= burn_kept of a
+ * [n_kept][d][n_chains] trace: d_mean, d_var are [d][n_chains]. */
+int mcmc_chain_moments(const double *d_trace, int32_t n_kept, int32_t burn_kept, int32_t d,
+                       int64_t n_chains, double *d_mean, double *d_var, void *stream);
+/* Reduces [d][n_chains] per-chain means/variances to d_partial[3*d + 1]:
+ * sum_c m, sum_c m^2, sum_c s^2 (per coordinate) and the chain count. */
+int mcmc_rhat_partial(const double *d_mean, const double *d_var, int32_t d, int64_t n_chains,
+                      double *d_partial, void *stream);
+/* Per-chain, per-coordinate effective sample size (Geyer initial positive sequence on the
+ * autocorrelation up to max_lag): d_ess is [d][n_chains]. */
+int mcmc_chain_ess(const double *d_trace, int32_t n_kept, int32_t burn_kept, int32_t d,
+                   int64_t n_chains, int32_t max_lag, double *d_ess, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCMC_AMD_H */

@@ -1,0 +1,136 @@
+"""ctypes binding of mcmc_amd/libmcmc_amd.so (the C ABI declared in include/mcmc_amd.h).
+
+There is no CPU fallback: if the HIP library is missing, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmcmc_amd.so")
+
+MCMC_OK = 0
+MCMC_E_BAD_ARG = -1
+MCMC_E_UNSUPPORTED = -2
+MCMC_E_HIP = -3
+MCMC_E_NOT_PD = -4
+MCMC_E_CHAIN_FAILED = -5
+
+MCMC_CHAIN_OK = 0
+MCMC_CHAIN_CHOL_FAILED = 1
+MCMC_CHAIN_NONFINITE_STATE = 2
+
+MCMC_RNG_PHILOX = 0
+MCMC_RNG_INJECTED = 1
+
+MCMC_TARGET_GAUSSIAN_PREC = 0
+MCMC_TARGET_GOLDSTEIN_PRICE = 1
+MCMC_TARGET_BANANA = 2
+
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int32)
+vp = C.c_void_p
+
+
+class McmcTarget(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("n_params", C.c_int32), ("h_params", dp)]
+
+
+class RwmConfig(C.Structure):
+    _fields_ = [
+        ("d", C.c_int32), ("n_iterations", C.c_int32),
+        ("n_chains", C.c_int64), ("chain_offset", C.c_int64),
+        ("adapt_size_start", C.c_int32), ("adapt_shape_start", C.c_int32),
+        ("acceptance_window", C.c_int32), ("thin", C.c_int32),
+        ("acceptance_rate_weight", C.c_double), ("adapt_size_cooling", C.c_double),
+        ("max_scaling_sd", C.c_double),
+        ("seed", C.c_uint64), ("rng_mode", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class RwmIO(C.Structure):
+    _fields_ = [
+        ("h_init_theta", dp), ("d_init", vp), ("h_covmat", dp), ("d_Z", vp), ("d_U", vp),
+        ("d_trace", vp), ("d_sigma_trace", vp), ("d_final_theta", vp), ("d_final_mean", vp),
+        ("d_final_cov", vp), ("d_acceptance_rate", vp), ("d_status", vp),
+        ("d_accepted", vp), ("d_log_acceptance", vp), ("d_log_A", vp), ("d_scaling_sd", vp),
+        ("d_scaling_multiplier", vp), ("d_rate_trace", vp),
+    ]
+
+
+class GibbsConfig(C.Structure):
+    _fields_ = [
+        ("d", C.c_int32), ("n_sweeps", C.c_int32),
+        ("n_chains", C.c_int64), ("chain_offset", C.c_int64),
+        ("thin", C.c_int32), ("burn", C.c_int32),
+        ("seed", C.c_uint64), ("rng_mode", C.c_int32), ("tail_safe", C.c_int32),
+    ]
+
+
+class GibbsIO(C.Structure):
+    _fields_ = [
+        ("h_mu", dp), ("h_sigma", dp), ("h_lower", dp), ("h_upper", dp), ("h_init_state", dp),
+        ("d_init", vp), ("d_U", vp), ("d_trace", vp), ("d_final_state", vp), ("d_mean", vp),
+        ("d_m2", vp), ("d_status", vp),
+    ]
+
+
+# every symbol include/mcmc_amd.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "mcmc_amd_abi_version": (C.c_int, []),
+    "mcmc_amd_last_error": (C.c_char_p, []),
+    "mcmc_amd_max_lane_dim": (C.c_int, []),
+    "mcmc_amd_max_dim": (C.c_int, []),
+    "mcmc_adapt_rwm_batch": (C.c_int, [C.POINTER(McmcTarget), C.POINTER(RwmConfig), C.POINTER(RwmIO), vp]),
+    "mcmc_rwm_streams": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, vp, vp]),
+    "mcmc_init_normal": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, C.c_int32, dp, C.c_double, vp, vp]),
+    "mcmc_adaptMCMC": (C.c_int, [C.POINTER(McmcTarget), C.c_int32, dp, dp, C.c_int32, C.c_int32, C.c_double,
+                                 C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, dp, dp,
+                                 dp, dp, dp, dp, ip]),
+    "mcmc_rwMCMC": (C.c_int, [C.POINTER(McmcTarget), C.c_int32, dp, dp, C.c_int32, C.c_int32, C.c_double, dp, dp,
+                              dp, dp, ip]),
+    "mcmc_tmvn_gibbs_batch": (C.c_int, [C.POINTER(GibbsConfig), C.POINTER(GibbsIO), vp]),
+    "mcmc_tmvn_precompute": (C.c_int, [C.c_int32, dp, dp, dp]),
+    "mcmc_gibbs_streams": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, vp]),
+    "mcmc_rtmvnorm_gibbs": (C.c_int, [C.c_int32, C.c_int32, dp, dp, dp, dp, dp, dp, C.c_uint64, dp]),
+    "mcmc_rtnorm_gibbs": (C.c_int, [C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, dp, C.c_uint64, dp]),
+    "mcmc_rtnorm_batch": (C.c_int, [C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, vp, C.c_uint64,
+                                    C.c_int64, C.c_int32, vp, vp]),
+    "mcmc_sub1": (C.c_int, [C.c_int32, dp, C.c_int32, dp]),
+    "mcmc_sub2": (C.c_int, [C.c_int32, C.c_int32, dp, C.c_int32, C.c_int32, dp]),
+    "mcmc_negSubCol": (C.c_int, [C.c_int32, dp, C.c_int32, dp]),
+    "mcmc_negSubRow": (C.c_int, [C.c_int32, dp, C.c_int32, dp]),
+    "mcmc_chain_moments": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int64, vp, vp, vp]),
+    "mcmc_rhat_partial": (C.c_int, [vp, vp, C.c_int32, C.c_int64, vp, vp]),
+    "mcmc_chain_ess": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, vp, vp]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP library is the product and has no CPU fallback. "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C mcmc_amd/csrc`)."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class McmcError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"mcmc_amd error {code}: {message}")
+        self.code = code
+
+
+def check(rc: int) -> None:
+    if rc != MCMC_OK:
+        raise McmcError(rc, lib.mcmc_amd_last_error().decode("utf-8", "replace"))

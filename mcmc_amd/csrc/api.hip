@@ -1,0 +1,491 @@
+// extern "C" entry points of libmcmc_amd.so (declared in include/mcmc_amd.h).
+//
+// Host side of the engine: argument validation (the reference has none, SURVEY.md
+// section 8b), the once-per-call shared precompute, kernel selection, and the host-pointer
+// single-chain wrappers that give the Rcpp shim the reference's own argument / return layout.
+#include <cstring>
+#include <limits>
+#include <string>
+
+#include "common.h"
+#include "host_linalg.h"
+#include "targets.h"
+
+namespace mcmc {
+
+static thread_local std::string g_last_error;
+
+int set_error(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+// RAII device buffer for the host-pointer wrappers
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <class T>
+    T *as() const { return (T *)p; }
+};
+
+static int build_rwm_params(const mcmc_target *target, int d, const double *h_init, const double *h_covmat,
+                            RwmParams &p)
+{
+    p.d = d;
+    p.target_kind = target->kind;
+    const int np = target_param_count(target->kind, d);
+    if (target->kind < 0 || target->kind > MCMC_TARGET_BANANA)
+        return set_error(MCMC_E_BAD_ARG, "unknown target kind %d", target->kind);
+    if (target->n_params != np || (np > 0 && !target->h_params))
+        return set_error(MCMC_E_BAD_ARG, "target kind %d with d=%d needs %d parameters, got %d", target->kind, d, np,
+                         target->n_params);
+    p.tparams.assign(target->h_params, target->h_params + np);
+    p.init.assign(d, 0.0);
+    if (h_init) p.init.assign(h_init, h_init + d);
+    // covmat: arma::chol reads the upper triangle only; det/inv in mvrnorm_pdf read all of it, so a
+    // non-symmetric covmat has no single meaning here and is rejected (the reference has no check).
+    double scale = 0.0;
+    for (int e = 0; e < d * d; ++e) {
+        if (!std::isfinite(h_covmat[e])) return set_error(MCMC_E_BAD_ARG, "covmat has a non-finite entry");
+        scale = std::fmax(scale, std::fabs(h_covmat[e]));
+    }
+    for (int r = 0; r < d; ++r)
+        for (int c = r + 1; c < d; ++c)
+            if (std::fabs(cmr(h_covmat, r, c, d) - cmr(h_covmat, c, r, d)) > 1e-12 * scale)
+                return set_error(MCMC_E_BAD_ARG, "covmat is not symmetric at (%d,%d)", r, c);
+    p.cov_packed.resize((size_t)d * (d + 1) / 2);
+    for (int c = 0; c < d; ++c)
+        for (int r = 0; r <= c; ++r) p.cov_packed[tri(r, c)] = cmr(h_covmat, r, c, d);
+    if (!chol_upper_packed(d, h_covmat, p.R0_packed, p.det0))
+        return set_error(MCMC_E_NOT_PD, "covmat is not positive definite (arma::chol would throw at iteration 1)");
+    return MCMC_OK;
+}
+
+static int build_gibbs_params(int d, const double *h_mu, const double *h_sigma, const double *h_lower,
+                              const double *h_upper, const double *h_init, GibbsParams &p)
+{
+    p.d = d;
+    p.mu.assign(h_mu, h_mu + d);
+    p.lower.assign(h_lower, h_lower + d);
+    p.upper.assign(h_upper, h_upper + d);
+    p.init.assign(d, 0.0);
+    if (h_init) p.init.assign(h_init, h_init + d);
+    p.sd.resize(d);
+    p.P.assign((size_t)d * (d > 1 ? d - 1 : 1), 0.0);
+    for (int k = 0; k < d; ++k) {
+        if (std::isnan(p.lower[k]) || std::isnan(p.upper[k]) || !(p.lower[k] < p.upper[k]))
+            return set_error(MCMC_E_BAD_ARG, "need lower[%d] < upper[%d]", k, k);
+        if (!std::isfinite(p.mu[k])) return set_error(MCMC_E_BAD_ARG, "mu[%d] is not finite", k);
+    }
+    for (int e = 0; e < d * d; ++e)
+        if (!std::isfinite(h_sigma[e])) return set_error(MCMC_E_BAD_ARG, "sigma has a non-finite entry");
+    // precision matrix H = sigma^-1; P_i = -H[i,-i] / H_ii, sd_i = 1 / sqrt(H_ii)
+    std::vector<double> H;
+    if (!spd_inverse(d, h_sigma, H)) return set_error(MCMC_E_NOT_PD, "sigma is not positive definite");
+    for (int i = 0; i < d; ++i) {
+        const double hii = H[(size_t)i * d + i];
+        p.sd[i] = 1.0 / std::sqrt(hii);
+        for (int k = 0, c = 0; k < d; ++k) {
+            if (k == i) continue;
+            p.P[(size_t)i * (d - 1) + c++] = -H[(size_t)k * d + i] / hii;
+        }
+    }
+    return MCMC_OK;
+}
+
+} // namespace mcmc
+
+using namespace mcmc;
+
+extern "C" int mcmc_amd_abi_version(void) { return MCMC_AMD_ABI_VERSION; }
+extern "C" const char *mcmc_amd_last_error(void) { return g_last_error.c_str(); }
+extern "C" int mcmc_amd_max_lane_dim(void) { return kMaxLaneDimRwm; }
+extern "C" int mcmc_amd_max_dim(void) { return kMaxDimGibbs; }
+
+// ============================================================================================
+extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_config *cfg, const mcmc_rwm_io *io,
+                                    void *stream)
+{
+    if (!target || !cfg || !io) return set_error(MCMC_E_BAD_ARG, "mcmc_adapt_rwm_batch: NULL argument");
+    const int d = cfg->d;
+    if (d < 1) return set_error(MCMC_E_BAD_ARG, "d=%d must be >= 1", d);
+    if (cfg->n_chains < 1) return set_error(MCMC_E_BAD_ARG, "n_chains=%lld must be >= 1", (long long)cfg->n_chains);
+    if (cfg->n_chains > (int64_t)64 * 0x7fffffff) return set_error(MCMC_E_BAD_ARG, "n_chains too large for one launch");
+    if (cfg->n_iterations < 1) return set_error(MCMC_E_BAD_ARG, "n_iterations=%d must be >= 1", cfg->n_iterations);
+    if (cfg->thin < 1) return set_error(MCMC_E_BAD_ARG, "thin=%d must be >= 1", cfg->thin);
+    if (cfg->adapt_size_start < 0 || cfg->adapt_shape_start < 0)
+        return set_error(MCMC_E_BAD_ARG, "adapt_size_start / adapt_shape_start must be >= 0");
+    if (cfg->acceptance_window < 0) return set_error(MCMC_E_BAD_ARG, "acceptance_window must be >= 0");
+    if (cfg->acceptance_window > 64)
+        return set_error(MCMC_E_UNSUPPORTED, "acceptance_window=%d: the device keeps at most 64 outcomes", cfg->acceptance_window);
+    if (std::isnan(cfg->acceptance_rate_weight) || std::isnan(cfg->adapt_size_cooling) || std::isnan(cfg->max_scaling_sd))
+        return set_error(MCMC_E_BAD_ARG, "NaN in the adaptation parameters");
+    if (!io->h_covmat) return set_error(MCMC_E_BAD_ARG, "h_covmat is NULL");
+    if (!io->h_init_theta && !io->d_init) return set_error(MCMC_E_BAD_ARG, "need h_init_theta or d_init");
+    if (cfg->rng_mode == MCMC_RNG_INJECTED) {
+        if (!io->d_Z || !io->d_U) return set_error(MCMC_E_BAD_ARG, "MCMC_RNG_INJECTED needs d_Z and d_U");
+    } else if (cfg->rng_mode != MCMC_RNG_PHILOX) {
+        return set_error(MCMC_E_BAD_ARG, "unknown rng_mode %d", cfg->rng_mode);
+    }
+    if (d > kMaxLaneDimRwm)
+        return set_error(MCMC_E_UNSUPPORTED, "adaptive RWM: d=%d above the lane-kernel limit %d", d, kMaxLaneDimRwm);
+
+    RwmParams p;
+    int rc = build_rwm_params(target, d, io->h_init_theta, io->h_covmat, p);
+    if (rc != MCMC_OK) return rc;
+
+    hipStream_t s = (hipStream_t)stream;
+    RwmArgs a{};
+    a.n_chains = cfg->n_chains;
+    a.chain_offset = cfg->chain_offset;
+    a.d = d;
+    a.n_iterations = cfg->n_iterations;
+    a.adapt_size_start = cfg->adapt_size_start;
+    a.adapt_shape_start = cfg->adapt_shape_start;
+    a.acceptance_window = cfg->acceptance_window;
+    a.thin = cfg->thin;
+    a.acceptance_rate_weight = cfg->acceptance_rate_weight;
+    a.max_scaling_sd = cfg->max_scaling_sd;
+    a.shape_scaling_sd = 2.38 / std::sqrt((double)d);
+    a.twopi_pow_d = std::pow(2 * M_PI, d);
+    a.seed = cfg->seed;
+    a.d_init = io->d_init;
+    const bool inject = cfg->rng_mode == MCMC_RNG_INJECTED;
+    a.d_Z = inject ? io->d_Z : nullptr;
+    a.d_U = inject ? io->d_U : nullptr;
+    a.d_trace = io->d_trace;
+    a.d_sigma_trace = io->d_sigma_trace;
+    a.d_final_theta = io->d_final_theta;
+    a.d_final_mean = io->d_final_mean;
+    a.d_final_cov = io->d_final_cov;
+    a.d_acceptance_rate = io->d_acceptance_rate;
+    a.d_status = io->d_status;
+    a.d_accepted = io->d_accepted;
+    a.d_log_acceptance = io->d_log_acceptance;
+    a.d_log_A = io->d_log_A;
+    a.d_scaling_sd = io->d_scaling_sd;
+    a.d_scaling_multiplier = io->d_scaling_multiplier;
+    a.d_rate_trace = io->d_rate_trace;
+
+    // pow(adapt_size_cooling, i - adapt_size_start) for i = 0..n (adaptMCMC_source.cpp:123), host libm
+    double *d_cool = nullptr;
+    if (cfg->adapt_size_start != 0) {
+        std::vector<double> cool((size_t)cfg->n_iterations + 1);
+        for (int i = 0; i <= cfg->n_iterations; ++i)
+            cool[i] = std::pow(cfg->adapt_size_cooling, i - cfg->adapt_size_start);
+        MCMC_HIP_CHECK(hipMallocAsync((void **)&d_cool, cool.size() * sizeof(double), s));
+        MCMC_HIP_CHECK(hipMemcpyAsync(d_cool, cool.data(), cool.size() * sizeof(double), hipMemcpyHostToDevice, s));
+        MCMC_HIP_CHECK(hipStreamSynchronize(s)); // `cool` is a local: do not let the copy outlive it
+        a.d_cool_pow = d_cool;
+    }
+    rc = launch_rwm_lane(a, p, s);
+    if (d_cool) {
+        hipError_t e = hipFreeAsync(d_cool, s);
+        if (rc == MCMC_OK && e != hipSuccess) rc = set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e));
+    }
+    return rc;
+}
+
+extern "C" int mcmc_rwm_streams(uint64_t seed, int64_t chain_offset, int64_t n_chains, int32_t n_iterations,
+                                int32_t d, double *d_Z, double *d_U, void *stream)
+{
+    if (n_chains < 1 || n_iterations < 1 || d < 1 || (!d_Z && !d_U))
+        return set_error(MCMC_E_BAD_ARG, "mcmc_rwm_streams: bad argument");
+    return launch_rwm_streams(seed, chain_offset, n_chains, n_iterations, d, d_Z, d_U, (hipStream_t)stream);
+}
+
+extern "C" int mcmc_init_normal(uint64_t seed, int64_t chain_offset, int64_t n_chains, int32_t d, const double *h_mean,
+                                double sd, double *d_out, void *stream)
+{
+    if (n_chains < 1 || d < 1 || !h_mean || !d_out) return set_error(MCMC_E_BAD_ARG, "mcmc_init_normal: bad argument");
+    return launch_init_normal(seed, chain_offset, n_chains, d, h_mean, sd, d_out, (hipStream_t)stream);
+}
+
+// --------------------------------------------------------------------------------------------
+static int run_single_rwm(const mcmc_target *target, int32_t d, const double *h_init_theta, const double *h_covmat,
+                          int32_t n, int32_t adapt_size_start, double weight, int32_t window, int32_t adapt_shape_start,
+                          int32_t info, double seedMH, double cooling, double max_sd, const double *h_Z,
+                          const double *h_U, double *h_theta_trace, double *h_sigma_empirical, double *h_acc,
+                          double *h_info_log, int32_t *fail_iter)
+{
+    if (fail_iter) *fail_iter = 0;
+    if (!target || !h_init_theta || !h_covmat || !h_theta_trace)
+        return set_error(MCMC_E_BAD_ARG, "NULL argument");
+    if (d < 1 || n < 1) return set_error(MCMC_E_BAD_ARG, "d and n_iterations must be >= 1");
+    if (info <= 0) return set_error(MCMC_E_BAD_ARG, "info=%d must be > 0 (the reference computes i %% info)", info);
+    if ((h_Z == nullptr) != (h_U == nullptr)) return set_error(MCMC_E_BAD_ARG, "give both h_Z and h_U, or neither");
+    if (!std::isfinite(seedMH) || seedMH < 0) return set_error(MCMC_E_BAD_ARG, "seedMH must be a finite non-negative number");
+
+    const size_t nd = (size_t)n * d, ndd = (size_t)n * d * d;
+    DevBuf bZ, bU, bT, bS, bAcc, bSt, bSd, bMul, bRate;
+    MCMC_HIP_CHECK(bT.alloc(nd * sizeof(double)));
+    MCMC_HIP_CHECK(bAcc.alloc(sizeof(double)));
+    MCMC_HIP_CHECK(bSt.alloc(sizeof(int32_t)));
+    if (h_sigma_empirical) MCMC_HIP_CHECK(bS.alloc(ndd * sizeof(double)));
+    if (h_Z) {
+        MCMC_HIP_CHECK(bZ.alloc(nd * sizeof(double)));
+        MCMC_HIP_CHECK(bU.alloc((size_t)n * sizeof(double)));
+        MCMC_HIP_CHECK(hipMemcpy(bZ.p, h_Z, nd * sizeof(double), hipMemcpyHostToDevice));
+        MCMC_HIP_CHECK(hipMemcpy(bU.p, h_U, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (h_info_log) {
+        MCMC_HIP_CHECK(bSd.alloc((size_t)n * sizeof(double)));
+        MCMC_HIP_CHECK(bMul.alloc((size_t)n * sizeof(double)));
+        MCMC_HIP_CHECK(bRate.alloc((size_t)n * sizeof(double)));
+    }
+    mcmc_rwm_config cfg{};
+    cfg.d = d;
+    cfg.n_iterations = n;
+    cfg.n_chains = 1;
+    cfg.chain_offset = 0;
+    cfg.adapt_size_start = adapt_size_start;
+    cfg.adapt_shape_start = adapt_shape_start;
+    cfg.acceptance_window = window;
+    cfg.thin = 1;
+    cfg.acceptance_rate_weight = weight;
+    cfg.adapt_size_cooling = cooling;
+    cfg.max_scaling_sd = max_sd;
+    cfg.seed = (uint64_t)seedMH; // std::mt19937 engine(seedMH): double -> unsigned (adaptMCMC_source.cpp:78)
+    cfg.rng_mode = h_Z ? MCMC_RNG_INJECTED : MCMC_RNG_PHILOX;
+    mcmc_rwm_io io{};
+    io.h_init_theta = h_init_theta;
+    io.h_covmat = h_covmat;
+    io.d_Z = bZ.as<double>();
+    io.d_U = bU.as<double>();
+    io.d_trace = bT.as<double>();
+    io.d_sigma_trace = h_sigma_empirical ? bS.as<double>() : nullptr;
+    io.d_acceptance_rate = bAcc.as<double>();
+    io.d_status = bSt.as<int32_t>();
+    if (h_info_log) {
+        io.d_scaling_sd = bSd.as<double>();
+        io.d_scaling_multiplier = bMul.as<double>();
+        io.d_rate_trace = bRate.as<double>();
+    }
+    int rc = mcmc_adapt_rwm_batch(target, &cfg, &io, nullptr);
+    if (rc != MCMC_OK) return rc;
+    MCMC_HIP_CHECK(hipDeviceSynchronize());
+
+    // [n][d][1] -> n x d column-major (arma::mat theta_trace, :92,185)
+    std::vector<double> tmp(nd);
+    MCMC_HIP_CHECK(hipMemcpy(tmp.data(), bT.p, nd * sizeof(double), hipMemcpyDeviceToHost));
+    for (int t = 0; t < n; ++t)
+        for (int k = 0; k < d; ++k) h_theta_trace[(size_t)k * n + t] = tmp[(size_t)t * d + k];
+    // [n][d*d][1] is already the arma::cube layout d x d x n (:93,214)
+    if (h_sigma_empirical) MCMC_HIP_CHECK(hipMemcpy(h_sigma_empirical, bS.p, ndd * sizeof(double), hipMemcpyDeviceToHost));
+    if (h_acc) MCMC_HIP_CHECK(hipMemcpy(h_acc, bAcc.p, sizeof(double), hipMemcpyDeviceToHost));
+    if (h_info_log) {
+        // what the reference prints at :142-146: the rate BEFORE iteration i's update, scaling_sd and
+        // scaling_multiplier after iteration i's adaptation block
+        std::vector<double> sd(n), mul(n), rate(n);
+        MCMC_HIP_CHECK(hipMemcpy(sd.data(), bSd.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+        MCMC_HIP_CHECK(hipMemcpy(mul.data(), bMul.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+        MCMC_HIP_CHECK(hipMemcpy(rate.data(), bRate.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+        for (int i = info; i <= n; i += info) {
+            double *row = h_info_log + (size_t)3 * (i / info - 1);
+            row[0] = i >= 2 ? rate[i - 2] : 0.0;
+            row[1] = sd[i - 1];
+            row[2] = mul[i - 1];
+        }
+    }
+    int32_t st = 0;
+    MCMC_HIP_CHECK(hipMemcpy(&st, bSt.p, sizeof st, hipMemcpyDeviceToHost));
+    if (st != MCMC_CHAIN_OK) {
+        if (fail_iter) *fail_iter = MCMC_STATUS_ITER(st);
+        return set_error(MCMC_E_CHAIN_FAILED, "chol(covmat_proposal) failed at iteration %d", MCMC_STATUS_ITER(st));
+    }
+    return MCMC_OK;
+}
+
+extern "C" int mcmc_adaptMCMC(const mcmc_target *target, int32_t d, const double *h_init_theta, const double *h_covmat,
+                              int32_t n_iterations, int32_t adapt_size_start, double acceptance_rate_weight,
+                              int32_t acceptance_window, int32_t adapt_shape_start, int32_t info, double seedMH,
+                              double adapt_size_cooling, double max_scaling_sd, const double *h_Z, const double *h_U,
+                              double *h_theta_trace, double *h_sigma_empirical, double *h_acceptance_rate,
+                              double *h_info_log, int32_t *fail_iter)
+{
+    return run_single_rwm(target, d, h_init_theta, h_covmat, n_iterations, adapt_size_start, acceptance_rate_weight,
+                          acceptance_window, adapt_shape_start, info, seedMH, adapt_size_cooling, max_scaling_sd, h_Z,
+                          h_U, h_theta_trace, h_sigma_empirical, h_acceptance_rate, h_info_log, fail_iter);
+}
+
+extern "C" int mcmc_rwMCMC(const mcmc_target *target, int32_t d, const double *h_init_theta, const double *h_covmat,
+                           int32_t n_iterations, int32_t info, double seedMH, const double *h_Z, const double *h_U,
+                           double *h_theta_trace, double *h_acceptance_rate, int32_t *fail_iter)
+{
+    return run_single_rwm(target, d, h_init_theta, h_covmat, n_iterations, 0, 0.0, 0, 0, info, seedMH, 0.99, 50.0, h_Z,
+                          h_U, h_theta_trace, nullptr, h_acceptance_rate, nullptr, fail_iter);
+}
+
+// ============================================================================================
+extern "C" int mcmc_tmvn_precompute(int32_t d, const double *h_sigma, double *h_P, double *h_sd)
+{
+    if (d < 1 || !h_sigma || !h_P || !h_sd) return set_error(MCMC_E_BAD_ARG, "mcmc_tmvn_precompute: bad argument");
+    std::vector<double> zeros(d, 0.0), lo(d, -1.0), hi(d, 1.0);
+    GibbsParams p;
+    int rc = build_gibbs_params(d, zeros.data(), h_sigma, lo.data(), hi.data(), nullptr, p);
+    if (rc != MCMC_OK) return rc;
+    std::memcpy(h_sd, p.sd.data(), sizeof(double) * d);
+    if (d > 1) std::memcpy(h_P, p.P.data(), sizeof(double) * (size_t)d * (d - 1));
+    return MCMC_OK;
+}
+
+extern "C" int mcmc_tmvn_gibbs_batch(const mcmc_gibbs_config *cfg, const mcmc_gibbs_io *io, void *stream)
+{
+    if (!cfg || !io) return set_error(MCMC_E_BAD_ARG, "mcmc_tmvn_gibbs_batch: NULL argument");
+    const int d = cfg->d;
+    if (d < 1 || d > kMaxDimGibbs) return set_error(d < 1 ? MCMC_E_BAD_ARG : MCMC_E_UNSUPPORTED, "d=%d outside 1..%d", d, kMaxDimGibbs);
+    if (cfg->n_chains < 1) return set_error(MCMC_E_BAD_ARG, "n_chains must be >= 1");
+    if (cfg->n_chains > (int64_t)64 * 0x7fffffff) return set_error(MCMC_E_BAD_ARG, "n_chains too large for one launch");
+    if (cfg->n_sweeps < 1) return set_error(MCMC_E_BAD_ARG, "n_sweeps must be >= 1");
+    if (cfg->thin < 1) return set_error(MCMC_E_BAD_ARG, "thin must be >= 1");
+    if (cfg->burn < 0) return set_error(MCMC_E_BAD_ARG, "burn must be >= 0");
+    if (!io->h_mu || !io->h_sigma || !io->h_lower || !io->h_upper) return set_error(MCMC_E_BAD_ARG, "mu/sigma/lower/upper missing");
+    if (!io->h_init_state && !io->d_init) return set_error(MCMC_E_BAD_ARG, "need h_init_state or d_init");
+    if ((io->d_mean == nullptr) != (io->d_m2 == nullptr)) return set_error(MCMC_E_BAD_ARG, "d_mean and d_m2 come as a pair");
+    if (cfg->rng_mode == MCMC_RNG_INJECTED) {
+        if (!io->d_U) return set_error(MCMC_E_BAD_ARG, "MCMC_RNG_INJECTED needs d_U");
+    } else if (cfg->rng_mode != MCMC_RNG_PHILOX) {
+        return set_error(MCMC_E_BAD_ARG, "unknown rng_mode %d", cfg->rng_mode);
+    }
+    GibbsParams p;
+    int rc = build_gibbs_params(d, io->h_mu, io->h_sigma, io->h_lower, io->h_upper, io->h_init_state, p);
+    if (rc != MCMC_OK) return rc;
+    GibbsArgs a{};
+    a.n_chains = cfg->n_chains;
+    a.chain_offset = cfg->chain_offset;
+    a.d = d;
+    a.n_sweeps = cfg->n_sweeps;
+    a.thin = cfg->thin;
+    a.burn = cfg->burn;
+    a.seed = cfg->seed;
+    a.d_init = io->d_init;
+    a.d_U = cfg->rng_mode == MCMC_RNG_INJECTED ? io->d_U : nullptr;
+    a.d_trace = io->d_trace;
+    a.d_final = io->d_final_state;
+    a.d_mean = io->d_mean;
+    a.d_m2 = io->d_m2;
+    a.d_status = io->d_status;
+    if (d <= kMaxLaneDimGibbs) return launch_gibbs_lane(a, p, cfg->tail_safe != 0, (hipStream_t)stream);
+    return launch_gibbs_lds(a, p, cfg->tail_safe != 0, (hipStream_t)stream);
+}
+
+extern "C" int mcmc_gibbs_streams(uint64_t seed, int64_t chain_offset, int64_t n_chains, int32_t n_sweeps, int32_t d,
+                                  double *d_U, void *stream)
+{
+    if (n_chains < 1 || n_sweeps < 1 || d < 1 || !d_U) return set_error(MCMC_E_BAD_ARG, "mcmc_gibbs_streams: bad argument");
+    return launch_gibbs_streams(seed, chain_offset, n_chains, n_sweeps, d, d_U, (hipStream_t)stream);
+}
+
+extern "C" int mcmc_rtmvnorm_gibbs(int32_t n, int32_t d, const double *h_mu, const double *h_sigma,
+                                   const double *h_lower, const double *h_upper, const double *h_init_state,
+                                   const double *h_U, uint64_t seed, double *h_trace)
+{
+    if (n < 1 || d < 1 || !h_mu || !h_sigma || !h_lower || !h_upper || !h_init_state || !h_trace)
+        return set_error(MCMC_E_BAD_ARG, "mcmc_rtmvnorm_gibbs: bad argument");
+    const size_t nd = (size_t)n * d;
+    DevBuf bU, bT;
+    MCMC_HIP_CHECK(bT.alloc(nd * sizeof(double)));
+    if (h_U) {
+        MCMC_HIP_CHECK(bU.alloc(nd * sizeof(double)));
+        MCMC_HIP_CHECK(hipMemcpy(bU.p, h_U, nd * sizeof(double), hipMemcpyHostToDevice));
+    }
+    mcmc_gibbs_config cfg{};
+    cfg.d = d;
+    cfg.n_sweeps = n;
+    cfg.n_chains = 1;
+    cfg.thin = 1;
+    cfg.seed = seed;
+    cfg.rng_mode = h_U ? MCMC_RNG_INJECTED : MCMC_RNG_PHILOX;
+    mcmc_gibbs_io io{};
+    io.h_mu = h_mu;
+    io.h_sigma = h_sigma;
+    io.h_lower = h_lower;
+    io.h_upper = h_upper;
+    io.h_init_state = h_init_state;
+    io.d_U = bU.as<double>();
+    io.d_trace = bT.as<double>();
+    int rc = mcmc_tmvn_gibbs_batch(&cfg, &io, nullptr);
+    if (rc != MCMC_OK) return rc;
+    MCMC_HIP_CHECK(hipDeviceSynchronize());
+    std::vector<double> tmp(nd);
+    MCMC_HIP_CHECK(hipMemcpy(tmp.data(), bT.p, nd * sizeof(double), hipMemcpyDeviceToHost));
+    for (int t = 0; t < n; ++t)
+        for (int k = 0; k < d; ++k) h_trace[(size_t)k * n + t] = tmp[(size_t)t * d + k]; // n x d column-major (:94,137)
+    return MCMC_OK;
+}
+
+extern "C" int mcmc_rtnorm_batch(int64_t n, double mu, double sigma, double a, double b, const double *d_F, uint64_t seed,
+                                 int64_t offset, int32_t tail_safe, double *d_out, void *stream)
+{
+    if (n < 0 || !d_out) return set_error(MCMC_E_BAD_ARG, "mcmc_rtnorm_batch: bad argument");
+    return launch_rtnorm(n, mu, sigma, a, b, d_F, seed, offset, tail_safe != 0, d_out, (hipStream_t)stream);
+}
+
+extern "C" int mcmc_rtnorm_gibbs(int32_t n, double mu, double sigma, double a, double b, const double *h_F, uint64_t seed,
+                                 double *h_out)
+{
+    if (n < 0 || (n > 0 && !h_out)) return set_error(MCMC_E_BAD_ARG, "mcmc_rtnorm_gibbs: bad argument");
+    if (n == 0) return MCMC_OK;
+    DevBuf bF, bO;
+    MCMC_HIP_CHECK(bO.alloc((size_t)n * sizeof(double)));
+    if (h_F) {
+        MCMC_HIP_CHECK(bF.alloc((size_t)n * sizeof(double)));
+        MCMC_HIP_CHECK(hipMemcpy(bF.p, h_F, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    }
+    int rc = launch_rtnorm(n, mu, sigma, a, b, bF.as<double>(), seed, 0, false, bO.as<double>(), nullptr);
+    if (rc != MCMC_OK) return rc;
+    MCMC_HIP_CHECK(hipDeviceSynchronize());
+    MCMC_HIP_CHECK(hipMemcpy(h_out, bO.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    return MCMC_OK;
+}
+
+// ============================================================================================
+// index-shedding helpers: pure host copies (on the device they are folded into indexing)
+extern "C" int mcmc_sub1(int32_t d, const double *h_x, int32_t i, double *h_out)
+{
+    if (d < 1 || !h_x || !h_out || i < 0 || i >= d) return set_error(MCMC_E_BAD_ARG, "mcmc_sub1: index %d outside 0..%d", i, d - 1);
+    const int m = d - 1;
+    for (int c = 0, oc = 0; c < d; ++c) {
+        if (c == i) continue;
+        for (int r = 0, orow = 0; r < d; ++r) {
+            if (r == i) continue;
+            h_out[(size_t)oc * m + orow++] = h_x[(size_t)c * d + r];
+        }
+        ++oc;
+    }
+    return MCMC_OK;
+}
+
+extern "C" int mcmc_sub2(int32_t nr, int32_t nc, const double *h_x, int32_t a, int32_t b, double *h_out)
+{
+    if (nr < 1 || nc < 1 || !h_x || !h_out || a < 0 || a >= nr || b < 0 || b >= nc)
+        return set_error(MCMC_E_BAD_ARG, "mcmc_sub2: index outside the matrix");
+    for (int c = 0, oc = 0; c < nc; ++c) {
+        if (c == b) continue;
+        h_out[oc++] = h_x[(size_t)c * nr + a];
+    }
+    return MCMC_OK;
+}
+
+extern "C" int mcmc_negSubCol(int32_t n, const double *h_x, int32_t i, double *h_out)
+{
+    if (n < 1 || !h_x || !h_out || i < 0 || i >= n) return set_error(MCMC_E_BAD_ARG, "negSub: index %d outside 0..%d", i, n - 1);
+    for (int k = 0, o = 0; k < n; ++k)
+        if (k != i) h_out[o++] = h_x[k];
+    return MCMC_OK;
+}
+
+extern "C" int mcmc_negSubRow(int32_t n, const double *h_x, int32_t i, double *h_out)
+{
+    return mcmc_negSubCol(n, h_x, i, h_out);
+}

@@ -1,0 +1,139 @@
+// Cross-chain convergence diagnostics on gfx950 (no counterpart in the reference: coda is
+// loaded at MCMCutilty.R:11 but never called).  These reduce a [n_kept][d][n_chains] trace to
+// the few numbers an RCCL all-reduce carries between GPUs.
+#include "common.h"
+
+namespace mcmc {
+
+// one thread per (chain, coordinate): Welford over kept draws t >= burn
+__global__ __launch_bounds__(256) void chain_moments_kernel(const double *__restrict__ trace, int32_t n_kept,
+                                                            int32_t burn, int32_t d, int64_t n, double *mean_out,
+                                                            double *var_out)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.y;
+    if (c >= n) return;
+    double mean = 0.0, m2 = 0.0;
+    int cnt = 0;
+    for (int t = burn; t < n_kept; ++t) {
+        const double x = trace[((int64_t)t * d + k) * n + c];
+        ++cnt;
+        const double delta = x - mean;
+        mean += delta / cnt;
+        m2 += delta * (x - mean);
+    }
+    mean_out[(int64_t)k * n + c] = mean;
+    var_out[(int64_t)k * n + c] = cnt > 1 ? m2 / (cnt - 1) : 0.0;
+}
+
+// one 1024-thread block per coordinate, fixed-order tree: deterministic sums over chains
+__global__ __launch_bounds__(1024) void rhat_partial_kernel(const double *__restrict__ mean, const double *__restrict__ var,
+                                                            int32_t d, int64_t n, double *partial)
+{
+    __shared__ double sm[3][1024];
+    const int k = blockIdx.x;
+    const int tid = threadIdx.x;
+    double a = 0.0, b = 0.0, s = 0.0;
+    for (int64_t c = tid; c < n; c += 1024) {
+        const double m = mean[(int64_t)k * n + c];
+        a += m;
+        b += m * m;
+        s += var[(int64_t)k * n + c];
+    }
+    sm[0][tid] = a;
+    sm[1][tid] = b;
+    sm[2][tid] = s;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (tid < off) {
+            sm[0][tid] += sm[0][tid + off];
+            sm[1][tid] += sm[1][tid + off];
+            sm[2][tid] += sm[2][tid + off];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        partial[k] = sm[0][0];
+        partial[d + k] = sm[1][0];
+        partial[2 * d + k] = sm[2][0];
+        if (k == 0) partial[3 * d] = (double)n;
+    }
+}
+
+// Geyer initial-positive-sequence ESS, one thread per (chain, coordinate)
+__global__ __launch_bounds__(256) void chain_ess_kernel(const double *__restrict__ trace, int32_t n_kept, int32_t burn,
+                                                        int32_t d, int64_t n, int32_t max_lag, double *ess_out)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.y;
+    if (c >= n) return;
+    const int N = n_kept - burn;
+    const double *x = trace + ((int64_t)burn * d + k) * n + c;
+    const int64_t stride = (int64_t)d * n;
+    double mean = 0.0;
+    for (int t = 0; t < N; ++t) mean += x[t * stride];
+    mean /= N;
+    double g0 = 0.0;
+    for (int t = 0; t < N; ++t) {
+        const double v = x[t * stride] - mean;
+        g0 += v * v;
+    }
+    double ess = 0.0;
+    if (g0 > 0.0 && N > 1) {
+        double tau = -1.0;
+        const int kmax = max_lag < N - 1 ? max_lag : N - 1;
+        for (int lag = 0; lag <= kmax; lag += 2) {
+            double ga = 0.0, gb = 0.0;
+            for (int t = 0; t + lag < N; ++t) {
+                const double v = x[t * stride] - mean;
+                ga += v * (x[(t + lag) * stride] - mean);
+                if (t + lag + 1 < N) gb += v * (x[(t + lag + 1) * stride] - mean);
+            }
+            if (lag + 1 > kmax) gb = 0.0;
+            const double pair = (ga + gb) / g0;
+            if (pair <= 0.0) break;
+            tau += 2.0 * pair;
+        }
+        ess = tau > 0.0 ? N / tau : (double)N;
+    }
+    ess_out[(int64_t)k * n + c] = ess;
+}
+
+} // namespace mcmc
+
+using namespace mcmc;
+
+extern "C" int mcmc_chain_moments(const double *d_trace, int32_t n_kept, int32_t burn_kept, int32_t d, int64_t n_chains,
+                                  double *d_mean, double *d_var, void *stream)
+{
+    if (!d_trace || !d_mean || !d_var || d < 1 || n_chains < 1 || burn_kept < 0 || n_kept <= burn_kept)
+        return set_error(MCMC_E_BAD_ARG, "mcmc_chain_moments: bad argument");
+    dim3 grid((unsigned)((n_chains + 255) / 256), (unsigned)d);
+    hipLaunchKernelGGL(chain_moments_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_trace, n_kept, burn_kept, d,
+                       n_chains, d_mean, d_var);
+    MCMC_HIP_CHECK(hipGetLastError());
+    return MCMC_OK;
+}
+
+extern "C" int mcmc_rhat_partial(const double *d_mean, const double *d_var, int32_t d, int64_t n_chains,
+                                 double *d_partial, void *stream)
+{
+    if (!d_mean || !d_var || !d_partial || d < 1 || n_chains < 1)
+        return set_error(MCMC_E_BAD_ARG, "mcmc_rhat_partial: bad argument");
+    hipLaunchKernelGGL(rhat_partial_kernel, dim3((unsigned)d), dim3(1024), 0, (hipStream_t)stream, d_mean, d_var, d,
+                       n_chains, d_partial);
+    MCMC_HIP_CHECK(hipGetLastError());
+    return MCMC_OK;
+}
+
+extern "C" int mcmc_chain_ess(const double *d_trace, int32_t n_kept, int32_t burn_kept, int32_t d, int64_t n_chains,
+                              int32_t max_lag, double *d_ess, void *stream)
+{
+    if (!d_trace || !d_ess || d < 1 || n_chains < 1 || burn_kept < 0 || n_kept <= burn_kept || max_lag < 1)
+        return set_error(MCMC_E_BAD_ARG, "mcmc_chain_ess: bad argument");
+    dim3 grid((unsigned)((n_chains + 255) / 256), (unsigned)d);
+    hipLaunchKernelGGL(chain_ess_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_trace, n_kept, burn_kept, d,
+                       n_chains, max_lag, d_ess);
+    MCMC_HIP_CHECK(hipGetLastError());
+    return MCMC_OK;
+}

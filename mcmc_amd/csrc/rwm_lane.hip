@@ -1,0 +1,367 @@
+// Adaptive random-walk Metropolis, one chain per lane, d <= 12 (gfx950).
+//
+// Replaces the main loop of adaptMCMC (adaptMCMC_source.cpp:108-216) and of rwMCMC
+// (:252-313; the same loop with both adapt_*_start = 0).  A wavefront advances 64 chains in
+// lockstep.  Per chain the kernel keeps in registers: theta, theta_mean, the packed upper
+// triangle of covmat_empirical, and the packed upper Cholesky factor R of covmat_proposal
+// (R^T R = covmat_proposal, as arma::chol returns it).  Everything shared by the chains
+// (covmat, chol(covmat), target parameters) is a by-value kernel argument and is read through
+// the scalar cache.
+//
+// What is done differently from the reference, and why it does not change results beyond
+// rounding:
+//   * chol(covmat_proposal) is recomputed only in iterations that assign covmat_proposal
+//     (:129,138); the reference refactors the unchanged matrix every iteration (:153).
+//   * the Hastings term mvrnorm_pdf (:48-64,169-170) needs det(Sigma) and v^T Sigma^-1 v with
+//     v = Y R: det = prod(diag R)^2 and v^T Sigma^-1 v = |Y|^2, so no LU det/inv is formed.  The
+//     term is still evaluated as log(rootTerm * exp(-q/2)), added and subtracted in that order,
+//     so the (la + p) - p rounding and the NaN-reject path when p is +-Inf are kept.
+//   * divisions by the iteration count in update_sigma (:43) and the mean update (:212) are
+//     multiplications by 1/i.
+// The acceptance-rate recurrences (:188-207) and the phase tests (:117,131) are evaluated
+// with the reference's exact operation sequence (no FMA contraction), because they feed
+// discrete decisions.
+#include "common.h"
+#include "philox.h"
+#include "targets.h"
+
+namespace mcmc {
+
+template <int D, int KIND>
+struct RwmShared {
+    static constexpr int T = D * (D + 1) / 2;
+    static constexpr int NP = target_param_count(KIND, D) > 0 ? target_param_count(KIND, D) : 1;
+    double init[D];
+    double cov[T]; // covmat_proposal_init, packed upper
+    double R0[T];  // chol(covmat), packed upper
+    double root0;  // 1 / sqrt((2 pi)^d det(covmat))
+    double tprm[NP];
+};
+
+template <int D, int KIND>
+__global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const RwmShared<D, KIND> sh)
+{
+    constexpr int T = D * (D + 1) / 2;
+    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (c >= a.n_chains) return;
+    const int64_t n = a.n_chains;
+    const uint64_t gchain = (uint64_t)(a.chain_offset + c);
+    const PhiloxKey key(a.seed);
+    const bool inject = a.d_Z != nullptr;
+    const int ass = a.adapt_size_start, ashs = a.adapt_shape_start;
+    const int window = a.acceptance_window;
+    const double w = a.acceptance_rate_weight;
+    const bool need_moments = ashs != 0 || a.d_sigma_trace || a.d_final_mean || a.d_final_cov;
+
+    double theta[D], mean[D], C[T], R[T];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        theta[k] = a.d_init ? a.d_init[(int64_t)k * n + c] : sh.init[k];
+        mean[k] = theta[k];
+    }
+#pragma unroll
+    for (int e = 0; e < T; ++e) {
+        C[e] = 0.0;
+        R[e] = sh.R0[e];
+    }
+    double rootTerm = sh.root0;
+    double t_cur = Target<KIND, D>::eval(theta, sh.tprm);
+    double rate = 0.0, scaling_sd = 1.0, scaling_multiplier = 1.0;
+    uint64_t win_bits = 0;
+    int win_len = 0;
+    int32_t status = MCMC_CHAIN_OK;
+    bool dead = false;
+
+    for (int i = 1; i <= a.n_iterations; ++i) {
+        const double di = (double)i;
+        // ---- adaptation of covmat_proposal (adaptMCMC_source.cpp:117-139) ------------------
+        bool dirty = false, use_emp = false;
+        double s2 = 0.0;
+        if (ass != 0 && i >= ass && (ashs == 0 || __dmul_rn(rate, di) < (double)ashs)) {
+            scaling_multiplier = exp(a.d_cool_pow[i] * (rate - 0.234));
+            scaling_sd = __dmul_rn(scaling_sd, scaling_multiplier);
+            scaling_sd = (a.max_scaling_sd < scaling_sd) ? a.max_scaling_sd : scaling_sd; // std::min
+            s2 = __dmul_rn(scaling_sd, scaling_sd);
+            bool any_small = false;
+#pragma unroll
+            for (int k = 0; k < D; ++k) any_small |= (__dmul_rn(s2, sh.cov[tri(k, k)]) < 2E-16);
+            dirty = !any_small;
+        } else if (ashs != 0 && __dmul_rn(rate, di) >= (double)ashs) {
+            scaling_sd = a.shape_scaling_sd;
+            s2 = __dmul_rn(scaling_sd, scaling_sd);
+            dirty = true;
+            use_emp = true;
+        }
+        if (a.d_scaling_sd) a.d_scaling_sd[(int64_t)(i - 1) * n + c] = scaling_sd;
+        if (a.d_scaling_multiplier) a.d_scaling_multiplier[(int64_t)(i - 1) * n + c] = scaling_multiplier;
+
+        // ---- R = chol(covmat_proposal) when it was assigned (:153) -------------------------
+        if (dirty && !dead) {
+            bool ok = true;
+            double prod = 1.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                double ajj = s2 * (use_emp ? C[tri(j, j)] : sh.cov[tri(j, j)]);
+#pragma unroll
+                for (int m = 0; m < j; ++m) ajj -= R[tri(m, j)] * R[tri(m, j)];
+                ok = ok && (ajj > 0.0);
+                const double rjj = sqrt(ajj);
+                const double rinv = 1.0 / rjj;
+                R[tri(j, j)] = rjj;
+                prod *= rjj;
+#pragma unroll
+                for (int k = j + 1; k < D; ++k) {
+                    double s = s2 * (use_emp ? C[tri(j, k)] : sh.cov[tri(j, k)]);
+#pragma unroll
+                    for (int m = 0; m < j; ++m) s -= R[tri(m, j)] * R[tri(m, k)];
+                    R[tri(j, k)] = s * rinv;
+                }
+            }
+            rootTerm = 1.0 / sqrt(a.twopi_pow_d * (prod * prod));
+            if (!ok) { // arma::chol throws here; the chain stops and reports where
+                dead = true;
+                status = (i << 4) | MCMC_CHAIN_CHOL_FAILED;
+#pragma unroll
+                for (int k = 0; k < D; ++k) theta[k] = __builtin_nan("");
+            }
+        }
+
+        // ---- proposal theta + Y * R (:149-154) ----------------------------------------------
+        double Y[D], prop[D];
+        if (inject) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) Y[k] = a.d_Z[((int64_t)(i - 1) * D + k) * n + c];
+        } else {
+#pragma unroll
+            for (int b = 0; 2 * b < D; ++b) {
+                double z0, z1;
+                philox_normal2(key, gchain, (uint32_t)i, TAG_RWM_NORMAL, (uint32_t)b, z0, z1);
+                Y[2 * b] = z0;
+                if (2 * b + 1 < D) Y[2 * b + 1] = z1;
+            }
+        }
+        double q = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k <= j; ++k) s += Y[k] * R[tri(k, j)];
+            prop[j] = theta[j] + s;
+            q += Y[j] * Y[j];
+        }
+
+        // ---- target and Metropolis-Hastings log ratio (:157-171) ----------------------------
+        const double t_prop = Target<KIND, D>::eval(prop, sh.tprm);
+        double la;
+        if (!isfinite(t_prop)) {
+            la = -__builtin_inf();
+        } else {
+            la = t_prop - t_cur;
+            const double p = log(rootTerm * exp(-0.5 * q)); // mvrnorm_pdf, both directions (:48-64)
+            la = __dadd_rn(la, p);
+            la = __dsub_rn(la, p);
+        }
+
+        // ---- accept / reject (:174-182) ------------------------------------------------------
+        double A;
+        if (inject) {
+            A = a.d_U[(int64_t)(i - 1) * n + c];
+        } else {
+            double u1;
+            philox_uniform2(key, gchain, (uint32_t)i, TAG_RWM_UNIFORM, 0u, A, u1);
+        }
+        const double logA = log(A);
+        const bool accept = logA < la;
+        if (accept) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) theta[k] = prop[k];
+            t_cur = t_prop;
+        }
+        if (a.d_accepted) a.d_accepted[(int64_t)(i - 1) * n + c] = accept ? 1 : 0;
+        if (a.d_log_acceptance) a.d_log_acceptance[(int64_t)(i - 1) * n + c] = la;
+        if (a.d_log_A) a.d_log_A[(int64_t)(i - 1) * n + c] = logA;
+
+        // ---- trace (:185) -------------------------------------------------------------------
+        const bool keep = (i % a.thin) == 0;
+        const int64_t t = i / a.thin - 1;
+        if (a.d_trace && keep) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) a.d_trace[(t * D + k) * n + c] = theta[k];
+        }
+
+        // ---- acceptance rate (:188-207) -----------------------------------------------------
+        const double acc = accept ? 1.0 : 0.0;
+        if (i == 1) {
+            rate = acc;
+        } else if (w == 0) {
+            if (window == 0) {
+                rate = __dadd_rn(rate, __ddiv_rn(__dsub_rn(acc, rate), di));
+            } else {
+                win_bits = (win_bits << 1) | (accept ? 1ull : 0ull);
+                if (win_len < window) ++win_len;
+                const uint64_t m = (win_len >= 64) ? ~0ull : ((1ull << win_len) - 1ull);
+                rate = __ddiv_rn((double)__popcll(win_bits & m), (double)win_len);
+            }
+        } else {
+            rate = __dadd_rn(__dmul_rn(rate, 1 - w), __dmul_rn(acc, w));
+        }
+        if (a.d_rate_trace) a.d_rate_trace[(int64_t)(i - 1) * n + c] = rate;
+
+        // ---- running mean / covariance (:210-214, update_sigma :42-45) ----------------------
+        if (need_moments) {
+            const double im1 = di - 1.0;
+            const double sfac = im1 / di;
+            const double inv_i = 1.0 / di;
+            double res[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) res[k] = theta[k] - mean[k];
+#pragma unroll
+            for (int cc = 0; cc < D; ++cc) {
+#pragma unroll
+                for (int r = 0; r <= cc; ++r)
+                    C[tri(r, cc)] = (C[tri(r, cc)] * im1 + (sfac * res[r]) * res[cc]) * inv_i;
+            }
+#pragma unroll
+            for (int k = 0; k < D; ++k) mean[k] += res[k] * inv_i;
+            if (a.d_sigma_trace && keep) {
+#pragma unroll
+                for (int cc = 0; cc < D; ++cc) {
+#pragma unroll
+                    for (int r = 0; r < D; ++r)
+                        a.d_sigma_trace[(t * (D * D) + cc * D + r) * n + c] = C[r <= cc ? tri(r, cc) : tri(cc, r)];
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        if (a.d_final_theta) a.d_final_theta[(int64_t)k * n + c] = theta[k];
+        if (a.d_final_mean) a.d_final_mean[(int64_t)k * n + c] = mean[k];
+    }
+    if (a.d_final_cov) {
+#pragma unroll
+        for (int cc = 0; cc < D; ++cc) {
+#pragma unroll
+            for (int r = 0; r < D; ++r)
+                a.d_final_cov[(int64_t)(cc * D + r) * n + c] = C[r <= cc ? tri(r, cc) : tri(cc, r)];
+        }
+    }
+    if (a.d_acceptance_rate) a.d_acceptance_rate[c] = rate;
+    if (a.d_status) a.d_status[c] = status;
+}
+
+// The normals / uniforms a Philox run draws: Z [n_iterations][d][n], U [n_iterations][n].
+__global__ __launch_bounds__(256) void rwm_streams_kernel(uint64_t seed, int64_t chain_offset, int64_t n,
+                                                          int32_t n_iterations, int32_t d, double *Z, double *U)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const PhiloxKey key(seed);
+    const uint64_t gchain = (uint64_t)(chain_offset + c);
+    for (int i = 1; i <= n_iterations; ++i) {
+        if (Z) {
+            for (int b = 0; 2 * b < d; ++b) {
+                double z0, z1;
+                philox_normal2(key, gchain, (uint32_t)i, TAG_RWM_NORMAL, (uint32_t)b, z0, z1);
+                Z[((int64_t)(i - 1) * d + 2 * b) * n + c] = z0;
+                if (2 * b + 1 < d) Z[((int64_t)(i - 1) * d + 2 * b + 1) * n + c] = z1;
+            }
+        }
+        if (U) {
+            double u0, u1;
+            philox_uniform2(key, gchain, (uint32_t)i, TAG_RWM_UNIFORM, 0u, u0, u1);
+            U[(int64_t)(i - 1) * n + c] = u0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void init_normal_kernel(uint64_t seed, int64_t chain_offset, int64_t n, int32_t d,
+                                                          const double *__restrict__ mean, double sd, double *out)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const PhiloxKey key(seed);
+    const uint64_t gchain = (uint64_t)(chain_offset + c);
+    for (int b = 0; 2 * b < d; ++b) {
+        double z0, z1;
+        philox_normal2(key, gchain, 0u, TAG_INIT, (uint32_t)b, z0, z1);
+        out[(int64_t)(2 * b) * n + c] = mean[2 * b] + sd * z0;
+        if (2 * b + 1 < d) out[(int64_t)(2 * b + 1) * n + c] = mean[2 * b + 1] + sd * z1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+template <int D, int KIND>
+static int launch_rwm_lane_dk(const RwmArgs &a, const RwmParams &p, hipStream_t s)
+{
+    using Sh = RwmShared<D, KIND>;
+    Sh sh;
+    for (int k = 0; k < D; ++k) sh.init[k] = p.init[k];
+    for (int e = 0; e < Sh::T; ++e) {
+        sh.cov[e] = p.cov_packed[e];
+        sh.R0[e] = p.R0_packed[e];
+    }
+    sh.root0 = 1.0 / std::sqrt(a.twopi_pow_d * p.det0);
+    sh.tprm[0] = 0.0;
+    const int np = target_param_count(KIND, D);
+    if ((int)p.tparams.size() != np)
+        return set_error(MCMC_E_BAD_ARG, "target kind %d with d=%d needs %d parameters, got %d", KIND, D, np,
+                         (int)p.tparams.size());
+    for (int e = 0; e < np; ++e) sh.tprm[e] = p.tparams[e];
+    const int64_t grid = (a.n_chains + 63) / 64;
+    hipLaunchKernelGGL((rwm_lane_kernel<D, KIND>), dim3((unsigned)grid), dim3(64), 0, s, a, sh);
+    MCMC_HIP_CHECK(hipGetLastError());
+    return MCMC_OK;
+}
+
+int launch_rwm_lane(const RwmArgs &a, const RwmParams &p, hipStream_t s)
+{
+    if (p.target_kind == MCMC_TARGET_GOLDSTEIN_PRICE) {
+        if (a.d != 2) return set_error(MCMC_E_BAD_ARG, "Goldstein-Price target is 2-dimensional (d=%d)", a.d);
+        return launch_rwm_lane_dk<2, MCMC_TARGET_GOLDSTEIN_PRICE>(a, p, s);
+    }
+    if (p.target_kind == MCMC_TARGET_BANANA) {
+        if (a.d != 2) return set_error(MCMC_E_BAD_ARG, "banana target is 2-dimensional (d=%d)", a.d);
+        return launch_rwm_lane_dk<2, MCMC_TARGET_BANANA>(a, p, s);
+    }
+    if (p.target_kind != MCMC_TARGET_GAUSSIAN_PREC)
+        return set_error(MCMC_E_BAD_ARG, "unknown target kind %d", p.target_kind);
+    switch (a.d) {
+#define MCMC_CASE(D) \
+    case D: return launch_rwm_lane_dk<D, MCMC_TARGET_GAUSSIAN_PREC>(a, p, s);
+        MCMC_CASE(1) MCMC_CASE(2) MCMC_CASE(3) MCMC_CASE(4) MCMC_CASE(5) MCMC_CASE(6)
+        MCMC_CASE(7) MCMC_CASE(8) MCMC_CASE(9) MCMC_CASE(10) MCMC_CASE(11) MCMC_CASE(12)
+#undef MCMC_CASE
+    default: return set_error(MCMC_E_UNSUPPORTED, "rwm lane kernel: d=%d outside 1..%d", a.d, kMaxLaneDimRwm);
+    }
+}
+
+int launch_rwm_streams(uint64_t seed, int64_t chain_offset, int64_t n_chains, int32_t n_iterations, int32_t d,
+                       double *d_Z, double *d_U, hipStream_t s)
+{
+    const int block = 256;
+    const int64_t grid = (n_chains + block - 1) / block;
+    hipLaunchKernelGGL(rwm_streams_kernel, dim3((unsigned)grid), dim3(block), 0, s, seed, chain_offset, n_chains,
+                       n_iterations, d, d_Z, d_U);
+    MCMC_HIP_CHECK(hipGetLastError());
+    return MCMC_OK;
+}
+
+int launch_init_normal(uint64_t seed, int64_t chain_offset, int64_t n_chains, int32_t d, const double *h_mean,
+                       double sd, double *d_out, hipStream_t s)
+{
+    double *d_mean = nullptr;
+    MCMC_HIP_CHECK(hipMallocAsync((void **)&d_mean, sizeof(double) * d, s));
+    MCMC_HIP_CHECK(hipMemcpyAsync(d_mean, h_mean, sizeof(double) * d, hipMemcpyHostToDevice, s));
+    MCMC_HIP_CHECK(hipStreamSynchronize(s)); // h_mean belongs to the caller
+    const int block = 256;
+    const int64_t grid = (n_chains + block - 1) / block;
+    hipLaunchKernelGGL(init_normal_kernel, dim3((unsigned)grid), dim3(block), 0, s, seed, chain_offset, n_chains, d,
+                       d_mean, sd, d_out);
+    MCMC_HIP_CHECK(hipGetLastError());
+    MCMC_HIP_CHECK(hipFreeAsync(d_mean, s));
+    return MCMC_OK;
+}
+
+} // namespace mcmc

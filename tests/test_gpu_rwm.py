@@ -1,0 +1,255 @@
+"""GPU parity: adaptive / plain random-walk Metropolis kernels (through the C ABI) vs the oracle.
+
+Bar (BASELINE.json north_star): with identical injected normal/uniform
+streams, accept/reject decisions match bit-exactly and trajectories agree within 1e-12 relative.
+Decision caveat written into the contract: the Hastings term p of mvrnorm_pdf comes from
+LAPACK det/inv in the reference, from LU in the oracle and from the Cholesky factor on the GPU,
+so a decision is only defined when |log A - la| > 1e-12 * max(1, |p|); closer calls are counted
+as indeterminate (none is expected at these sizes) -- never silently accepted.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+RTOL = 1e-12
+
+
+def _rel(a, b):
+    return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
+
+
+def _check_decisions(got_acc, ref_diag):
+    """bit-exact decisions, except where the margin is inside the contract's indeterminate band"""
+    ref_acc = ref_diag["accepted"]
+    diff = np.nonzero(got_acc != ref_acc)[0]
+    if diff.size == 0:
+        return 0
+    margin = np.abs(ref_diag["log_A"] - ref_diag["log_acceptance"])
+    p = np.abs(np.nan_to_num(ref_diag["pdf_term"], nan=0.0, posinf=0.0, neginf=0.0))
+    first = diff[0]
+    assert margin[first] <= 1e-12 * max(1.0, p[first]), f"decision {first} differs with margin {margin[first]}"
+    return diff.size
+
+
+def _gauss(d, rho, rng=None):
+    idx = np.arange(d)
+    Sig = rho ** np.abs(idx[:, None] - idx[None, :])
+    H = np.linalg.inv(Sig)
+    return Sig, 0.5 * (H + H.T)
+
+
+@pytest.mark.parametrize("name", ["banana", "goldpr"])
+def test_adaptMCMC_reference_examples_single_chain(cuda, oracle, name):
+    """adaptMCMC_analysis.R:19-28 (banana) and :115-134 (Goldstein-Price), injected streams."""
+    import mcmc_amd
+
+    g = np.load(os.path.join(GOLD, f"g5_adapt_{name}.npz"))
+    n = int(g["n"])
+    tgt = mcmc_amd.Target.banana(0.03) if name == "banana" else mcmc_amd.Target.goldstein_price()
+    r = mcmc_amd.adaptMCMC(tgt, g["init"], np.eye(2), n, int(g["adapt_size_start"]), 0.0, 0,
+                           int(g["adapt_shape_start"]), 100, 123.0, Z=g["Z"], U=g["U"], info_log=True)
+    assert r["theta_trace"].shape == (n, 2) and r["sigma_empirical"].shape == (2, 2, n)
+    assert _rel(r["theta_trace"], g["theta_trace"]) < RTOL
+    assert r["acceptance_rate"] == float(g["acceptance_rate"])  # same decisions -> same recurrence, bit for bit
+    assert _rel(r["sigma_empirical"][:, :, -1], g["sigma_last"]) < 1e-11
+    assert _rel(r["sigma_empirical"][:, :, 99::100], g["sigma_every100"]) < 1e-11
+    # what the reference prints every `info` iterations (:142-146)
+    il = r["info_log"]
+    assert il.shape == (n // 100, 3)
+    np.testing.assert_array_equal(il[:, 0], g["rate"][98::100][: il.shape[0]])
+    np.testing.assert_allclose(il[:, 1], g["scaling_sd"][99::100], rtol=1e-13)
+
+
+def test_adapt_batch_d10_decisions_and_trajectories(cuda, oracle):
+    """Config-2 shape (10-D correlated Gaussian, adapt 100/500 scaled down), 192 chains."""
+    import mcmc_amd
+
+    d, nc, n = 10, 192, 1500
+    rng = np.random.default_rng(42)
+    Sig, H = _gauss(d, 0.9)
+    init = 2.0 * rng.standard_normal((d, nc))
+    Z = rng.standard_normal((n, d, nc))
+    U = rng.random((n, nc))
+    out = mcmc_amd.adapt_rwm_batch(mcmc_amd.Target.gaussian(np.zeros(d), H), nc, cuda.tensor(init, device="cuda"),
+                                   np.eye(d), n, 100, 0.0, 0, 300, Z=cuda.tensor(Z, device="cuda"),
+                                   U=cuda.tensor(U, device="cuda"), diagnostics=True)
+    cuda.cuda.synchronize()
+    assert np.all(out["status"].cpu().numpy() == 0)
+    tr = out["theta_trace"].cpu().numpy()
+    acc = out["accepted"].cpu().numpy()
+    sd = out["scaling_sd"].cpu().numpy()
+    rate = out["rate_trace"].cpu().numpy()
+    la = out["log_acceptance"].cpu().numpy()
+    indeterminate = 0
+    for c in (0, 63, 64, 100, 191):
+        ref = oracle.adaptMCMC(oracle.gaussian_target(np.zeros(d), H), init[:, c], np.eye(d), n, 100, 0.0, 0, 300,
+                               Z[:, :, c], U[:, c], diagnostics=True)
+        k = _check_decisions(acc[:, c], ref["diag"])
+        indeterminate += k
+        if k:
+            continue
+        assert _rel(tr[:, :, c], ref["theta_trace"]) < RTOL, c
+        np.testing.assert_array_equal(rate[:, c], ref["diag"]["acceptance_rate"])
+        np.testing.assert_allclose(sd[:, c], ref["diag"]["scaling_sd"], rtol=1e-12)
+        fin = np.isfinite(ref["diag"]["log_acceptance"])
+        np.testing.assert_allclose(la[fin, c], ref["diag"]["log_acceptance"][fin], rtol=0,
+                                   atol=1e-10 * np.maximum(1, np.abs(ref["diag"]["pdf_term"][fin])).max())
+        assert out["acceptance_rate"].cpu().numpy()[c] == ref["acceptance_rate"]
+        np.testing.assert_allclose(out["final_cov"].cpu().numpy()[:, c].reshape(d, d, order="F"),
+                                   ref["sigma_empirical"][:, :, -1], rtol=1e-10, atol=1e-13)
+        np.testing.assert_array_equal(out["final_theta"].cpu().numpy()[:, c], tr[-1, :, c])
+        # shape phase reached, so the whole adaptation path was exercised
+        assert ref["diag"]["scaling_sd"][-1] == pytest.approx(2.38 / np.sqrt(d))
+    assert indeterminate == 0
+
+
+@pytest.mark.parametrize("tag,w,win", [("mean", 0.0, 0), ("weight", 0.05, 0), ("window", 0.0, 50)])
+def test_three_acceptance_rate_modes(cuda, tag, w, win):
+    """adaptMCMC_source.cpp:188-207 against the committed oracle vectors."""
+    import mcmc_amd
+
+    g = np.load(os.path.join(GOLD, "g6_rate_modes.npz"))
+    n, d = int(g["n"]), 3
+    out = mcmc_amd.adapt_rwm_batch(mcmc_amd.Target.gaussian(np.zeros(d), g["H"]), 1, g["init"], np.eye(d), n, 50, w, win,
+                                   200, Z=cuda.tensor(g["Z"].reshape(n, d, 1), device="cuda"),
+                                   U=cuda.tensor(g["U"].reshape(n, 1), device="cuda"), diagnostics=True)
+    np.testing.assert_array_equal(out["accepted"].cpu().numpy()[:, 0], g[f"accepted_{tag}"])
+    np.testing.assert_array_equal(out["rate_trace"].cpu().numpy()[:, 0], g[f"rate_{tag}"])
+    np.testing.assert_allclose(out["scaling_sd"].cpu().numpy()[:, 0], g[f"scaling_sd_{tag}"], rtol=1e-12)
+    assert _rel(out["theta_trace"].cpu().numpy()[:, :, 0], g[f"trace_{tag}"]) < RTOL
+
+
+def test_nan_and_minus_inf_reject_paths(cuda):
+    """Far jump: exp(-q/2) underflows, p = -Inf, la = NaN, `log(A) < NaN` is false -> reject.
+    Overflowing target: -Inf -> immediate reject (adaptMCMC_source.cpp:163-171)."""
+    import mcmc_amd
+
+    g = np.load(os.path.join(GOLD, "g7_nan_paths.npz"))
+    n = int(g["n"])
+    r = mcmc_amd.rwMCMC(mcmc_amd.Target.gaussian(np.zeros(2), np.eye(2)), g["init"], np.eye(2), n, 10, 1.0, Z=g["Z"],
+                        U=g["U"])
+    assert _rel(r["theta_trace"], g["theta_trace"]) < RTOL
+    assert r["acceptance_rate"] == float(g["acceptance_rate"])
+    out = mcmc_amd.adapt_rwm_batch(mcmc_amd.Target.gaussian(np.zeros(2), np.eye(2)), 1, g["init"], np.eye(2), n,
+                                   Z=cuda.tensor(g["Z"].reshape(n, 2, 1), device="cuda"),
+                                   U=cuda.tensor(g["U"].reshape(n, 1), device="cuda"), diagnostics=True)
+    la = out["log_acceptance"].cpu().numpy()[:, 0]
+    assert np.isnan(la[10]) and la[50] == -np.inf
+    np.testing.assert_array_equal(out["accepted"].cpu().numpy()[:, 0], g["accepted"])
+
+
+def test_chol_failure_is_reported_per_chain(cuda):
+    """Shape adaptation with a rank-deficient covmat_empirical: arma::chol throws in the reference
+    (adaptMCMC_source.cpp:153); the engine reports the iteration in the status word."""
+    import mcmc_amd
+
+    g = np.load(os.path.join(GOLD, "g8_chol_fail.npz"))
+    n, d = int(g["n"]), 3
+    tgt = mcmc_amd.Target.gaussian(np.zeros(d), np.eye(d))
+    out = mcmc_amd.adapt_rwm_batch(tgt, 1, np.zeros(d), np.eye(d), n, 0, 0.0, 0, 1,
+                                   Z=cuda.tensor(g["Z"].reshape(n, d, 1), device="cuda"),
+                                   U=cuda.tensor(g["U"].reshape(n, 1), device="cuda"))
+    st = int(out["status"].cpu().numpy()[0])
+    assert (st & 15) == mcmc_amd.MCMC_CHAIN_CHOL_FAILED and (st >> 4) == int(g["fail_iter"])
+    tr = out["theta_trace"].cpu().numpy()[:, :, 0]
+    fi = int(g["fail_iter"])
+    np.testing.assert_allclose(tr[: fi - 1], g["theta_trace"][: fi - 1], rtol=1e-13)
+    assert np.all(np.isnan(tr[fi - 1:]))
+    with pytest.raises(mcmc_amd.McmcError) as e:
+        mcmc_amd.adaptMCMC(tgt, np.zeros(d), np.eye(d), n, 0, 0.0, 0, 1, 10, 1.0, Z=g["Z"], U=g["U"])
+    assert e.value.code == -5
+    # not-PD covmat: the reference would throw at iteration 1; the engine refuses up front
+    with pytest.raises(mcmc_amd.McmcError) as e:
+        mcmc_amd.rwMCMC(tgt, np.zeros(d), -np.eye(d), 10, 1, 1.0)
+    assert e.value.code == -4
+
+
+def test_rwMCMC_plain_random_walk(cuda, oracle):
+    import mcmc_amd
+
+    rng = np.random.default_rng(77)
+    d, n = 5, 800
+    Sig, H = _gauss(d, 0.5)
+    cov = 0.3 * Sig
+    Z, U = rng.standard_normal((n, d)), rng.random(n)
+    r = mcmc_amd.rwMCMC(mcmc_amd.Target.gaussian(np.ones(d), H), np.zeros(d), cov, n, 100, 5.0, Z=Z, U=U)
+    ref = oracle.rwMCMC(oracle.gaussian_target(np.ones(d), H), np.zeros(d), cov, n, Z, U)
+    assert _rel(r["theta_trace"], ref["theta_trace"]) < RTOL
+    assert r["acceptance_rate"] == ref["acceptance_rate"]
+
+
+def test_philox_run_replays_through_oracle(cuda, oracle):
+    """A Philox-mode run equals the oracle fed with the streams mcmc_rwm_streams reports."""
+    import mcmc_amd
+
+    d, nc, n = 4, 130, 600
+    Sig, H = _gauss(d, 0.7)
+    tgt = mcmc_amd.Target.gaussian(np.zeros(d), H)
+    out = mcmc_amd.adapt_rwm_batch(tgt, nc, np.ones(d), np.eye(d), n, 50, 0.0, 0, 150, seed=31, chain_offset=1000,
+                                   diagnostics=True)
+    Z, U = mcmc_amd.rwm_streams(31, nc, n, d, chain_offset=1000)
+    Z, U = Z.cpu().numpy(), U.cpu().numpy()
+    assert U.min() > 0 and U.max() < 1 and abs(Z.mean()) < 0.01 and abs(Z.std() - 1) < 0.01
+    tr = out["theta_trace"].cpu().numpy()
+    acc = out["accepted"].cpu().numpy()
+    for c in (0, 64, 129):
+        ref = oracle.adaptMCMC(oracle.gaussian_target(np.zeros(d), H), np.ones(d), np.eye(d), n, 50, 0.0, 0, 150,
+                               Z[:, :, c], U[:, c], diagnostics=True, store_sigma=False)
+        assert _check_decisions(acc[:, c], ref["diag"]) == 0
+        assert _rel(tr[:, :, c], ref["theta_trace"]) < RTOL
+
+
+def test_results_do_not_depend_on_sharding_and_thinning(cuda):
+    import mcmc_amd
+
+    d = 6
+    Sig, H = _gauss(d, 0.6)
+    tgt = mcmc_amd.Target.gaussian(np.zeros(d), H)
+    kw = dict(adapt_size_start=20, adapt_shape_start=60, seed=5)
+    whole = mcmc_amd.adapt_rwm_batch(tgt, 160, np.zeros(d), np.eye(d), 300, **kw)["theta_trace"]
+    part = mcmc_amd.adapt_rwm_batch(tgt, 96, np.zeros(d), np.eye(d), 300, chain_offset=64, **kw)["theta_trace"]
+    assert cuda.equal(whole[:, :, 64:], part)
+    thin = mcmc_amd.adapt_rwm_batch(tgt, 160, np.zeros(d), np.eye(d), 300, thin=10, **kw)["theta_trace"]
+    assert thin.shape[0] == 30 and cuda.equal(thin, whole[9::10])
+
+
+def test_philox_gaussian_target_moments_and_ks(cuda):
+    """Philox run on N(0, Sigma): pooled per-coordinate KS test, mean and covariance against the
+    target the reference's own samples converge to (north_star correctness part 2)."""
+    import mcmc_amd
+    from scipy import stats
+
+    d, nc, n = 3, 2048, 3000
+    Sig, H = _gauss(d, 0.5)
+    out = mcmc_amd.adapt_rwm_batch(mcmc_amd.Target.gaussian(np.zeros(d), H), nc, np.zeros(d), np.eye(d), n, 50, 0.0, 0,
+                                   200, seed=2024, thin=50)
+    x = out["theta_trace"][20:].cpu().numpy()  # [t, d, chains] after burn-in, thinned
+    flat = np.moveaxis(x, 1, 2).reshape(-1, d)
+    np.testing.assert_allclose(flat.mean(0), 0.0, atol=0.02)
+    np.testing.assert_allclose(np.cov(flat.T), Sig, atol=0.03)
+    for k in range(d):
+        s = x[-1, k, :]  # one draw per chain: independent
+        assert stats.kstest(s, stats.norm(0, np.sqrt(Sig[k, k])).cdf).pvalue > 1e-3
+    rate = out["acceptance_rate"].cpu().numpy()
+    assert 0.15 < rate.mean() < 0.5
+
+
+def test_init_normal_and_argument_validation(cuda):
+    import mcmc_amd
+
+    x = mcmc_amd.init_normal(1, 50_000, [1.0, -2.0, 3.0], 2.0).cpu().numpy()
+    np.testing.assert_allclose(x.mean(1), [1.0, -2.0, 3.0], atol=0.05)
+    np.testing.assert_allclose(x.std(1), 2.0, atol=0.05)
+    tgt = mcmc_amd.Target.gaussian(np.zeros(2), np.eye(2))
+    with pytest.raises(TypeError):
+        mcmc_amd.rwMCMC(lambda th: -0.5 * th @ th, [0, 0], np.eye(2), 10, 1, 1.0)  # R-closure analogue
+    with pytest.raises(mcmc_amd.McmcError):
+        mcmc_amd.rwMCMC(tgt, [0, 0], np.eye(2), 10, 0, 1.0)  # info = 0: UB in the reference (:261)
+    with pytest.raises(mcmc_amd.McmcError):
+        mcmc_amd.rwMCMC(tgt, [0, 0], np.array([[1.0, 0.5], [0.2, 1.0]]), 10, 1, 1.0)  # asymmetric covmat
+    with pytest.raises(mcmc_amd.McmcError):
+        mcmc_amd.adapt_rwm_batch(mcmc_amd.Target.goldstein_price(), 4, np.zeros(3), np.eye(3), 10)  # d != 2
