@@ -3,6 +3,7 @@
 // Host side of the engine: argument validation (the reference has none, SURVEY.md
 // section 8b), the once-per-call shared precompute, kernel selection, and the host-pointer
 // single-chain wrappers that give the Rcpp shim the reference's own argument / return layout.
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -375,8 +376,7 @@ extern "C" int mcmc_tmvn_gibbs_batch(const mcmc_gibbs_config *cfg, const mcmc_gi
     a.d_mean = io->d_mean;
     a.d_m2 = io->d_m2;
     a.d_status = io->d_status;
-    if (d <= kMaxLaneDimGibbs) return launch_gibbs_lane(a, p, cfg->tail_safe != 0, (hipStream_t)stream);
-    return launch_gibbs_lds(a, p, cfg->tail_safe != 0, (hipStream_t)stream);
+    return launch_gibbs(a, p, cfg->tail_safe != 0, (hipStream_t)stream);
 }
 
 extern "C" int mcmc_gibbs_streams(uint64_t seed, int64_t chain_offset, int64_t n_chains, int32_t n_sweeps, int32_t d,

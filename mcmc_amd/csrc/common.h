@@ -14,7 +14,6 @@ namespace mcmc {
 
 // largest d handled by the register-resident one-chain-per-lane kernels
 constexpr int kMaxLaneDimRwm = 12;
-constexpr int kMaxLaneDimGibbs = 16;
 // largest d of the LDS-resident kernels (one 64-lane workgroup must fit 160 KiB of LDS)
 constexpr int kMaxDimGibbs = 256;
 constexpr int kMaxDimRwm = 128;
@@ -53,8 +52,7 @@ struct GibbsParams {
     std::vector<double> mu, sd, lower, upper, init, P;
 };
 
-int launch_gibbs_lane(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipStream_t s);
-int launch_gibbs_lds(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipStream_t s);
+int launch_gibbs(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipStream_t s);
 int launch_gibbs_streams(uint64_t seed, int64_t chain_offset, int64_t n_chains, int32_t n_sweeps,
                          int32_t d, double *d_U, hipStream_t s);
 int launch_rtnorm(int64_t n, double mu, double sigma, double a, double b, const double *d_F,

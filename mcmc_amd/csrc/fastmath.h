@@ -1,0 +1,123 @@
+// Lean FP64 device math for the gfx950 MCMC kernels.
+//
+// Measured on MI355X (tools/ubench_isa.hip, cycles per wave-instruction at full occupancy):
+// v_fma_f64 4.8, v_rcp/rsq_f64 16.3, IEEE a/b 61, ocml log 360, ocml sqrt 93, ocml sincospi 193,
+// ocml exp 97.  The sampling kernels are bound by exactly these sequences, so the hot ones are
+// restated here with <= 1-2 ulp error and without the range handling the kernels do not need:
+//   fm_log      ~120 cycles   (fdlibm-style: frexp, s = f/(2+f), degree-7 polynomial in s^2)
+//   fm_sqrt_rsq  ~55 cycles   (v_rsq_f64 + two coupled Newton steps; returns sqrt AND 1/sqrt)
+//   fm_div       ~40 cycles   (v_rcp_f64 + two Newton steps, no final rounding fix-up)
+//   fm_sincospi_quarter ~70   (|r| <= 1/4 only; the caller picks the quadrant from random bits)
+// All results are compared with the CPU oracle to 1e-12 relative in tests/.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mcmc {
+
+// Single IEEE operations that the compiler may NOT contract into FMAs: the acceptance-rate
+// recurrences of adaptMCMC feed discrete decisions (rate * i >= adapt_shape_start), so they
+// must round exactly like the reference's separate multiply / add / divide.
+__device__ __forceinline__ double mul_rn(double a, double b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ double add_rn(double a, double b)
+{
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ double div_rn(double a, double b)
+{
+#pragma clang fp contract(off)
+    return a / b;
+}
+
+// a / b for finite, normal, well-scaled operands; error <= ~1.5 ulp.
+__device__ __forceinline__ double fm_rcp(double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    double e = fma(-b, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-b, r, 1.0);
+    r = fma(r, e, r);
+    return r;
+}
+__device__ __forceinline__ double fm_div(double a, double b) { return a * fm_rcp(b); }
+
+// sqrt(x) and 1/sqrt(x) for normal x > 0 (x = 0 gives NaN: callers test x > 0 first).
+__device__ __forceinline__ void fm_sqrt_rsq(double x, double &s, double &rs)
+{
+    const double y = __builtin_amdgcn_rsq(x); // ~24 good bits
+    double g = x * y;
+    double h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); // ~48 bits
+    h = fma(h, r, h);
+    const double d = fma(-g, g, x);
+    g = fma(d, h, g); // full precision
+    r = fma(-h, g, 0.5);
+    h = fma(h, r, h);
+    s = g;
+    rs = h + h;
+}
+__device__ __forceinline__ double fm_sqrt(double x)
+{
+    double s, rs;
+    fm_sqrt_rsq(x, s, rs);
+    return s;
+}
+
+// natural log.  FULL = true handles 0, +Inf, NaN and negatives like libm;
+// FULL = false assumes a positive finite argument (uniforms in (0,1), tail probabilities).
+template <bool FULL>
+__device__ __forceinline__ double fm_log(double x)
+{
+    int e;
+    double m = frexp(x, &e); // m in [0.5, 1); v_frexp_* normalise subnormals themselves
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    const double f = m - 1.0;
+    const double s = f * fm_rcp(2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+    const double t2 = z * (6.666666666666735130e-01 +
+                           w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)e;
+    double res = dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+    if (FULL) {
+        if (x == 0.0) res = -__builtin_inf();
+        if (x < 0.0 || x != x) res = __builtin_nan("");
+        if (x == __builtin_inf()) res = x;
+    }
+    return res;
+}
+
+// sin(pi r), cos(pi r) for |r| <= 1/4 (near-minimax fits in r^2, max error 2.2e-16).
+__device__ __forceinline__ void fm_sincospi_quarter(double r, double &s, double &c)
+{
+    const double t = r * r;
+    double ps = 0.000461531855383581;
+    ps = fma(ps, t, -0.007370021586907771);
+    ps = fma(ps, t, 0.08214586918000175);
+    ps = fma(ps, t, -0.5992645289396449);
+    ps = fma(ps, t, 2.5501640398733763);
+    ps = fma(ps, t, -5.167712780049954);
+    ps = fma(ps, t, 3.141592653589793);
+    double pc = -0.00010356747255199479;
+    pc = fma(pc, t, 0.0019294657440800042);
+    pc = fma(pc, t, -0.025806885652951306);
+    pc = fma(pc, t, 0.23533063019088787);
+    pc = fma(pc, t, -1.3352627688519174);
+    pc = fma(pc, t, 4.058712126416747);
+    pc = fma(pc, t, -4.934802200544679);
+    pc = fma(pc, t, 1.0);
+    s = r * ps;
+    c = pc;
+}
+
+} // namespace mcmc

@@ -3,101 +3,29 @@
 // Replaces the sweep loop of rtmvnorm_gibbs (tmvrnormGibbs.cpp:115-139) and the draw loop of
 // rtnorm_gibbs (:58-67).  One chain per lane: a wavefront advances 64 independent chains in
 // lockstep, so the 2 x pnorm + qnorm work of every coordinate (about 70 % of a sweep) runs on
-// all 64 lanes.  Coordinates inside a sweep are visited in order (Gauss-Seidel), as the
-// reference does.
+// all 64 lanes; a wavefront-per-chain layout would leave 63 of 64 lanes idle there.
+// Coordinates inside a sweep are visited in order (Gauss-Seidel), as the reference does.
 //
-//   gibbs_lane_kernel<D>   d <= 16: the state x[D] lives in VGPRs (loops fully unrolled);
-//                          the shared parameters (mu, sd, bounds, regression rows P_i) are a
-//                          by-value kernel argument, i.e. they are read through the scalar
-//                          cache into SGPRs.
-//   gibbs_lds_kernel       any d up to 256: centred state x - mu in LDS, laid out [k][lane]
-//                          (ds_read_b64 / ds_write_b64, bank = lane, conflict free); shared
-//                          parameters come from HBM through wave-uniform (scalar) loads.
-//
-// Samples leave as one coalesced store per coordinate and kept sweep: trace[(t*d+k)*n + c],
-// 512 contiguous bytes per wavefront.
+// Data layout
+//   * chain state: the centred vector x - mu in LDS as [k][lane] (d * 512 B per wavefront;
+//     ds_read_b64 / ds_write_b64 with bank = lane, conflict free).  d = 10 -> 5 KiB per wave, so
+//     eight waves per SIMD fit in the 160 KiB of a CU; d = 128 -> 64 KiB, two waves per CU.
+//   * shared parameters (mu, sd, bounds, regression rows P_i): one block in HBM, read with
+//     wave-uniform addresses, i.e. through the scalar cache into SGPRs (s_load_dwordx*), and
+//     used directly as the scalar operand of v_fma_f64.  The offset `z` below is an opaque zero
+//     refreshed every sweep: it keeps the compiler from hoisting ~200 parameter SGPRs out of
+//     the loop and then spilling them to VGPR lanes (v_readlane in the hot loop).
+//   * samples: one coalesced store per coordinate and kept sweep, trace[(t*d+k)*n + c] --
+//     512 contiguous bytes per wavefront.
 #include "common.h"
 #include "normal_cdf.h"
 #include "philox.h"
 
 namespace mcmc {
 
-template <int D>
-struct GibbsShared {
-    double mu[D], sd[D], lower[D], upper[D], init[D];
-    double P[(D > 1) ? D * (D - 1) : 1];
-};
-
-template <int D, bool TAIL_SAFE>
-__global__ __launch_bounds__(256) void gibbs_lane_kernel(const GibbsArgs a, const GibbsShared<D> sh)
-{
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= a.n_chains) return;
-    const int64_t n = a.n_chains;
-    const uint64_t gchain = (uint64_t)(a.chain_offset + c);
-    const PhiloxKey key(a.seed);
-    const bool inject = a.d_U != nullptr;
-    const bool moments = a.d_mean != nullptr || a.d_m2 != nullptr;
-
-    double x[D], mean[D], m2[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        x[k] = a.d_init ? a.d_init[(int64_t)k * n + c] : sh.init[k];
-        mean[k] = 0.0;
-        m2[k] = 0.0;
-    }
-    int32_t status = MCMC_CHAIN_OK;
-
-    for (int j = 1; j <= a.n_sweeps; ++j) {
-        double ua = 0.0, ub = 0.0;
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-            double u;
-            if (inject) {
-                u = a.d_U[((int64_t)(j - 1) * D + i) * n + c];
-            } else {
-                if ((i & 1) == 0) philox_uniform2(key, gchain, (uint32_t)j, TAG_GIBBS, (uint32_t)(i >> 1), ua, ub);
-                u = (i & 1) ? ub : ua;
-            }
-            // conditional mean: mu_i + P_i (x[-i] - mu[-i])   (tmvrnormGibbs.cpp:124-127)
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-                if (k == i) continue;
-                s += sh.P[i * (D - 1) + (k < i ? k : k - 1)] * (x[k] - sh.mu[k]);
-            }
-            const double mu_i = sh.mu[i] + s;
-            const double xi = rtnorm_draw<TAIL_SAFE>(u, mu_i, sh.sd[i], sh.lower[i], sh.upper[i]);
-            x[i] = xi;
-            if (!isfinite(xi) && status == MCMC_CHAIN_OK) status = (j << 4) | MCMC_CHAIN_NONFINITE_STATE;
-        }
-        if (a.d_trace && (j % a.thin) == 0) {
-            const int64_t t = j / a.thin - 1;
-#pragma unroll
-            for (int k = 0; k < D; ++k) a.d_trace[(t * D + k) * n + c] = x[k];
-        }
-        if (moments && j > a.burn) {
-            const double inv = 1.0 / (double)(j - a.burn);
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-                const double delta = x[k] - mean[k];
-                mean[k] += delta * inv;
-                m2[k] += delta * (x[k] - mean[k]);
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        if (a.d_final) a.d_final[(int64_t)k * n + c] = x[k];
-        if (a.d_mean) a.d_mean[(int64_t)k * n + c] = mean[k];
-        if (a.d_m2) a.d_m2[(int64_t)k * n + c] = m2[k];
-    }
-    if (a.d_status) a.d_status[c] = status;
-}
-
-// parameter block in HBM for the LDS kernel: mu[d] sd[d] lower[d] upper[d] init[d] P[d*(d-1)]
-template <bool TAIL_SAFE>
-__global__ __launch_bounds__(64) void gibbs_lds_kernel(const GibbsArgs a, const double *__restrict__ prm)
+// parameter block: mu[d] sd[d] lower[d] upper[d] init[d] inv_sd[d] P[d*(d-1)]
+template <bool TAIL_SAFE, bool MOMENTS>
+__global__ __launch_bounds__(64, 3) void gibbs_kernel(const GibbsArgs a, const double *__restrict__ prm)
 {
     extern __shared__ double xc[]; // centred state, [k][lane]
     const int lane = threadIdx.x;
@@ -106,21 +34,14 @@ __global__ __launch_bounds__(64) void gibbs_lds_kernel(const GibbsArgs a, const 
     const bool live = c < n;
     const int64_t cc = live ? c : n - 1; // tail lanes shadow the last chain and store nothing
     const int d = a.d;
-    const double *__restrict__ mu = prm;
-    const double *__restrict__ sd = prm + d;
-    const double *__restrict__ lower = prm + 2 * d;
-    const double *__restrict__ upper = prm + 3 * d;
-    const double *__restrict__ init = prm + 4 * d;
-    const double *__restrict__ P = prm + 5 * d;
     const uint64_t gchain = (uint64_t)(a.chain_offset + cc);
     const PhiloxKey key(a.seed);
     const bool inject = a.d_U != nullptr;
-    const bool moments = a.d_mean != nullptr; // d_mean and d_m2 are validated as a pair on the host
 
     for (int k = 0; k < d; ++k) {
-        const double x0 = a.d_init ? a.d_init[(int64_t)k * n + cc] : init[k];
-        xc[k * 64 + lane] = x0 - mu[k];
-        if (moments && live) {
+        const double x0 = a.d_init ? a.d_init[(int64_t)k * n + cc] : prm[4 * d + k];
+        xc[k * 64 + lane] = x0 - prm[k];
+        if (MOMENTS && live) {
             a.d_mean[(int64_t)k * n + c] = 0.0;
             a.d_m2[(int64_t)k * n + c] = 0.0;
         }
@@ -128,9 +49,17 @@ __global__ __launch_bounds__(64) void gibbs_lds_kernel(const GibbsArgs a, const 
     int32_t status = MCMC_CHAIN_OK;
 
     for (int j = 1; j <= a.n_sweeps; ++j) {
+        int z = 0;
+        asm volatile("" : "+s"(z)); // opaque zero: parameter loads stay inside the sweep loop
+        const double *__restrict__ mu = prm + z;
+        const double *__restrict__ sd = mu + d;
+        const double *__restrict__ lower = mu + 2 * d;
+        const double *__restrict__ upper = mu + 3 * d;
+        const double *__restrict__ inv_sd = mu + 5 * d;
+        const double *__restrict__ P = mu + 6 * d;
         const bool keep = a.d_trace && (j % a.thin) == 0;
         const int64_t t = j / a.thin - 1;
-        const bool mom = moments && j > a.burn;
+        const bool mom = MOMENTS && j > a.burn;
         const double inv = mom ? 1.0 / (double)(j - a.burn) : 0.0;
         double ua = 0.0, ub = 0.0;
         for (int i = 0; i < d; ++i) {
@@ -141,12 +70,13 @@ __global__ __launch_bounds__(64) void gibbs_lds_kernel(const GibbsArgs a, const 
                 if ((i & 1) == 0) philox_uniform2(key, gchain, (uint32_t)j, TAG_GIBBS, (uint32_t)(i >> 1), ua, ub);
                 u = (i & 1) ? ub : ua;
             }
+            // conditional mean mu_i + P_i (x[-i] - mu[-i])   (tmvrnormGibbs.cpp:124-127)
             const double *__restrict__ Pi = P + (int64_t)i * (d - 1);
             double s = 0.0;
             for (int k = 0; k < i; ++k) s += Pi[k] * xc[k * 64 + lane];
             for (int k = i + 1; k < d; ++k) s += Pi[k - 1] * xc[k * 64 + lane];
             const double mu_i = mu[i] + s;
-            const double xi = rtnorm_draw<TAIL_SAFE>(u, mu_i, sd[i], lower[i], upper[i]);
+            const double xi = rtnorm_draw_std<TAIL_SAFE>(u, mu_i, sd[i], inv_sd[i], lower[i], upper[i]);
             xc[i * 64 + lane] = xi - mu[i];
             if (!isfinite(xi) && status == MCMC_CHAIN_OK) status = (j << 4) | MCMC_CHAIN_NONFINITE_STATE;
             if (live) {
@@ -163,11 +93,7 @@ __global__ __launch_bounds__(64) void gibbs_lds_kernel(const GibbsArgs a, const 
             }
         }
     }
-    if (live) {
-        if (a.n_sweeps == 0 && a.d_final)
-            for (int k = 0; k < d; ++k) a.d_final[(int64_t)k * n + c] = xc[k * 64 + lane] + mu[k];
-        if (a.d_status) a.d_status[c] = status;
-    }
+    if (live && a.d_status) a.d_status[c] = status;
 }
 
 // uniforms a Philox Gibbs run draws, [n_sweeps][d][n_chains]
@@ -215,52 +141,18 @@ __global__ __launch_bounds__(256) void rtnorm_kernel(int64_t n, double mu, doubl
 }
 
 // ------------------------------------------------------------------------------------------
-template <int D>
-static int launch_gibbs_lane_d(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipStream_t s)
-{
-    GibbsShared<D> sh;
-    for (int k = 0; k < D; ++k) {
-        sh.mu[k] = p.mu[k];
-        sh.sd[k] = p.sd[k];
-        sh.lower[k] = p.lower[k];
-        sh.upper[k] = p.upper[k];
-        sh.init[k] = p.init[k];
-    }
-    sh.P[0] = 0.0;
-    for (int e = 0; e < D * (D - 1); ++e) sh.P[e] = p.P[e];
-    const int block = 256;
-    const int64_t grid = (a.n_chains + block - 1) / block;
-    if (tail_safe)
-        hipLaunchKernelGGL((gibbs_lane_kernel<D, true>), dim3((unsigned)grid), dim3(block), 0, s, a, sh);
-    else
-        hipLaunchKernelGGL((gibbs_lane_kernel<D, false>), dim3((unsigned)grid), dim3(block), 0, s, a, sh);
-    MCMC_HIP_CHECK(hipGetLastError());
-    return MCMC_OK;
-}
-
-int launch_gibbs_lane(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipStream_t s)
-{
-    switch (a.d) {
-#define MCMC_CASE(D) \
-    case D: return launch_gibbs_lane_d<D>(a, p, tail_safe, s);
-        MCMC_CASE(1) MCMC_CASE(2) MCMC_CASE(3) MCMC_CASE(4) MCMC_CASE(5) MCMC_CASE(6) MCMC_CASE(7) MCMC_CASE(8)
-        MCMC_CASE(9) MCMC_CASE(10) MCMC_CASE(11) MCMC_CASE(12) MCMC_CASE(13) MCMC_CASE(14) MCMC_CASE(15) MCMC_CASE(16)
-#undef MCMC_CASE
-    default: return set_error(MCMC_E_UNSUPPORTED, "gibbs lane kernel: d=%d outside 1..%d", a.d, kMaxLaneDimGibbs);
-    }
-}
-
-int launch_gibbs_lds(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipStream_t s)
+int launch_gibbs(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipStream_t s)
 {
     const int d = a.d;
     if (d < 1 || d > kMaxDimGibbs) return set_error(MCMC_E_UNSUPPORTED, "gibbs: d=%d outside 1..%d", d, kMaxDimGibbs);
     std::vector<double> blob;
-    blob.reserve((size_t)5 * d + (size_t)d * (d - 1));
+    blob.reserve((size_t)6 * d + (size_t)d * (d - 1));
     blob.insert(blob.end(), p.mu.begin(), p.mu.end());
     blob.insert(blob.end(), p.sd.begin(), p.sd.end());
     blob.insert(blob.end(), p.lower.begin(), p.lower.end());
     blob.insert(blob.end(), p.upper.begin(), p.upper.end());
     blob.insert(blob.end(), p.init.begin(), p.init.end());
+    for (int k = 0; k < d; ++k) blob.push_back(1.0 / p.sd[k]);
     blob.insert(blob.end(), p.P.begin(), p.P.begin() + (size_t)d * (d - 1));
     double *d_prm = nullptr;
     MCMC_HIP_CHECK(hipMallocAsync((void **)&d_prm, blob.size() * sizeof(double), s));
@@ -268,18 +160,21 @@ int launch_gibbs_lds(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, h
     MCMC_HIP_CHECK(hipStreamSynchronize(s)); // blob is a local: do not let the copy outlive it
     const size_t lds = (size_t)d * 64 * sizeof(double);
     const int64_t grid = (a.n_chains + 63) / 64;
-    if (tail_safe) {
-        MCMC_HIP_CHECK(hipFuncSetAttribute((const void *)gibbs_lds_kernel<true>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((gibbs_lds_kernel<true>), dim3((unsigned)grid), dim3(64), lds, s, a, d_prm);
-    } else {
-        MCMC_HIP_CHECK(hipFuncSetAttribute((const void *)gibbs_lds_kernel<false>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((gibbs_lds_kernel<false>), dim3((unsigned)grid), dim3(64), lds, s, a, d_prm);
-    }
-    MCMC_HIP_CHECK(hipGetLastError());
-    MCMC_HIP_CHECK(hipFreeAsync(d_prm, s));
-    return MCMC_OK;
+    const bool moments = a.d_mean != nullptr;
+    auto go = [&](auto kern) -> int {
+        MCMC_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, s, a, (const double *)d_prm);
+        MCMC_HIP_CHECK(hipGetLastError());
+        return MCMC_OK;
+    };
+    int rc;
+    if (tail_safe)
+        rc = moments ? go(gibbs_kernel<true, true>) : go(gibbs_kernel<true, false>);
+    else
+        rc = moments ? go(gibbs_kernel<false, true>) : go(gibbs_kernel<false, false>);
+    hipError_t e = hipFreeAsync(d_prm, s);
+    if (rc == MCMC_OK && e != hipSuccess) rc = set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e));
+    return rc;
 }
 
 int launch_gibbs_streams(uint64_t seed, int64_t chain_offset, int64_t n_chains, int32_t n_sweeps, int32_t d,

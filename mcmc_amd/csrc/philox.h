@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "fastmath.h"
+
 namespace mcmc {
 
 enum PhiloxTag : uint32_t {
@@ -78,22 +80,32 @@ __device__ inline void philox_uniform2(const PhiloxKey &key, uint64_t chain, uin
     u1 = u01_from_bits(r.z, r.w);
 }
 
-// Box-Muller: two independent N(0,1) from the two uniforms of one Philox block.
-__device__ inline void box_muller(double u0, double u1, double &z0, double &z1)
+// Box-Muller: two independent N(0,1) from the 128 bits of one Philox block.
+//   radius: R = sqrt(-2 log u0), u0 in (0,1) from words x,y (52 bits)
+//   angle : uniform on the circle, built as pi*r + k*pi/2 with the quadrant k from the top two bits
+//           of word z and r in (-1/4, 1/4) from the next 52 bits of (z,w): no range reduction needed.
+__device__ inline void box_muller_bits(const u32x4 &b, double &z0, double &z1)
 {
-    double r = sqrt(-2.0 * log(u0));
+    const double u0 = u01_from_bits(b.x, b.y);
+    const double R = fm_sqrt(-2.0 * fm_log<false>(u0));
+    const uint32_t k = b.z >> 30;
+    const double f = u01_from_bits(b.z << 2 | b.w >> 30, b.w << 2); // 52 of the remaining 62 bits
     double s, c;
-    sincospi(2.0 * u1, &s, &c);
-    z0 = r * c;
-    z1 = r * s;
+    fm_sincospi_quarter(0.5 * f - 0.25, s, c);
+    // rotate by k quarter turns
+    const double s1 = (k & 1) ? c : s;
+    const double c1 = (k & 1) ? -s : c;
+    const double sg = (k & 2) ? -1.0 : 1.0;
+    z0 = R * (sg * c1);
+    z1 = R * (sg * s1);
 }
 
 __device__ inline void philox_normal2(const PhiloxKey &key, uint64_t chain, uint32_t iteration,
                                       uint32_t tag, uint32_t block, double &z0, double &z1)
 {
-    double u0, u1;
-    philox_uniform2(key, chain, iteration, tag, block, u0, u1);
-    box_muller(u0, u1, z0, z1);
+    const u32x4 r = philox4x32_10((uint32_t)chain, (uint32_t)(chain >> 32), iteration, (tag << 16) | block,
+                                  key.k0, key.k1);
+    box_muller_bits(r, z0, z1);
 }
 
 } // namespace mcmc

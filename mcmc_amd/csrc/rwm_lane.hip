@@ -2,11 +2,12 @@
 //
 // Replaces the main loop of adaptMCMC (adaptMCMC_source.cpp:108-216) and of rwMCMC
 // (:252-313; the same loop with both adapt_*_start = 0).  A wavefront advances 64 chains in
-// lockstep.  Per chain the kernel keeps in registers: theta, theta_mean, the packed upper
-// triangle of covmat_empirical, and the packed upper Cholesky factor R of covmat_proposal
-// (R^T R = covmat_proposal, as arma::chol returns it).  Everything shared by the chains
-// (covmat, chol(covmat), target parameters) is a by-value kernel argument and is read through
-// the scalar cache.
+// lockstep.  Per chain the kernel keeps theta and the packed upper Cholesky factor R of
+// covmat_proposal (R^T R = covmat_proposal, as arma::chol returns it) in VGPRs, and theta_mean
+// plus the packed upper triangle of covmat_empirical in LDS as [element][lane] (touched once per
+// iteration; bank = lane, conflict free).  Everything shared by the chains (covmat, chol(covmat),
+// target parameters) is one small block staged into LDS at kernel start and read with
+// same-address (broadcast) LDS loads.
 //
 // What is done differently from the reference, and why it does not change results beyond
 // rounding:
@@ -17,7 +18,8 @@
 //     term is still evaluated as log(rootTerm * exp(-q/2)), added and subtracted in that order,
 //     so the (la + p) - p rounding and the NaN-reject path when p is +-Inf are kept.
 //   * divisions by the iteration count in update_sigma (:43) and the mean update (:212) are
-//     multiplications by 1/i.
+//     multiplications by 1/i; sqrt / reciprocal pivots / log use the lean sequences of fastmath.h
+//     (<= 1-2 ulp).
 // The acceptance-rate recurrences (:188-207) and the phase tests (:117,131) are evaluated
 // with the reference's exact operation sequence (no FMA contraction), because they feed
 // discrete decisions.
@@ -27,45 +29,68 @@
 
 namespace mcmc {
 
+// parameter block in HBM (doubles): init[D] cov[T] R0[T] root0 tprm[NP]; T = D(D+1)/2.
+// cov = covmat_proposal_init and R0 = chol(covmat), both packed upper: (r,c), r<=c at c(c+1)/2+r.
 template <int D, int KIND>
-struct RwmShared {
+struct RwmLayout {
     static constexpr int T = D * (D + 1) / 2;
-    static constexpr int NP = target_param_count(KIND, D) > 0 ? target_param_count(KIND, D) : 1;
-    double init[D];
-    double cov[T]; // covmat_proposal_init, packed upper
-    double R0[T];  // chol(covmat), packed upper
-    double root0;  // 1 / sqrt((2 pi)^d det(covmat))
-    double tprm[NP];
+    static constexpr int NP = target_param_count(KIND, D);
+    static constexpr int INIT = 0, COV = D, R0 = D + T, ROOT0 = D + 2 * T, TPRM = D + 2 * T + 1;
+    static constexpr int TOTAL = TPRM + NP;
+    static constexpr int SH = (TOTAL + 1) & ~1;       // shared parameters staged in LDS (16-B aligned size)
+    static constexpr int LDS_DOUBLES = SH + (T + D) * 64; // + covmat_empirical and theta_mean as [e][lane]
 };
 
-template <int D, int KIND>
-__global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const RwmShared<D, KIND> sh)
+// view of the target parameters inside the block, indexable like an array
+struct PrmView {
+    const double *p;
+    __device__ __forceinline__ double operator[](int i) const { return p[i]; }
+};
+
+// FULL = false is the production variant (Philox streams; theta trace, final state and per-chain
+// summaries only).  FULL = true adds injected streams, the sigma_empirical trace and the per-iteration
+// parity diagnostics; keeping those ~250 extra store addresses out of the production kernel is what
+// keeps its scalar registers from spilling.
+template <int D, int KIND, bool FULL>
+__global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const double *__restrict__ prm)
 {
-    constexpr int T = D * (D + 1) / 2;
-    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (c >= a.n_chains) return;
+    using Lay = RwmLayout<D, KIND>;
+    constexpr int T = Lay::T;
+    extern __shared__ double lds[]; // shared parameters, then C[e][lane] for e < T, then mean[k][lane]
+    const int lane = threadIdx.x;
+    const int64_t c = (int64_t)blockIdx.x * 64 + lane;
     const int64_t n = a.n_chains;
-    const uint64_t gchain = (uint64_t)(a.chain_offset + c);
+    const bool live = c < n;
+    const int64_t cc = live ? c : n - 1; // tail lanes shadow the last chain and store nothing
+    const uint64_t gchain = (uint64_t)(a.chain_offset + cc);
     const PhiloxKey key(a.seed);
-    const bool inject = a.d_Z != nullptr;
+    const bool inject = FULL && a.d_Z != nullptr;
     const int ass = a.adapt_size_start, ashs = a.adapt_shape_start;
     const int window = a.acceptance_window;
     const double w = a.acceptance_rate_weight;
-    const bool need_moments = ashs != 0 || a.d_sigma_trace || a.d_final_mean || a.d_final_cov;
+    const bool need_moments = ashs != 0 || (FULL && a.d_sigma_trace) || a.d_final_mean || a.d_final_cov;
+    // Stage the shared parameter block in LDS: the target alone needs d + d^2 values per iteration,
+    // more than the ~100 SGPRs of a wave, so scalar loads would be spilled to VGPR lanes; from LDS
+    // they arrive as same-address (broadcast) reads.
+    for (int e = lane; e < Lay::TOTAL; e += 64) lds[e] = prm[e];
+    __syncthreads();
+    const double *const sh = lds;
+    double *const Cl = lds + Lay::SH + lane;          // C element e at Cl[e * 64]
+    double *const Ml = lds + Lay::SH + T * 64 + lane; // mean element k at Ml[k * 64]
 
-    double theta[D], mean[D], C[T], R[T];
+    double theta[D], R[T];
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-        theta[k] = a.d_init ? a.d_init[(int64_t)k * n + c] : sh.init[k];
-        mean[k] = theta[k];
+        theta[k] = a.d_init ? a.d_init[(int64_t)k * n + cc] : sh[Lay::INIT + k];
+        Ml[k * 64] = theta[k];
     }
 #pragma unroll
     for (int e = 0; e < T; ++e) {
-        C[e] = 0.0;
-        R[e] = sh.R0[e];
+        Cl[e * 64] = 0.0;
+        R[e] = sh[Lay::R0 + e];
     }
-    double rootTerm = sh.root0;
-    double t_cur = Target<KIND, D>::eval(theta, sh.tprm);
+    double rootTerm = sh[Lay::ROOT0];
+    double t_cur = Target<KIND, D>::eval(theta, PrmView{sh + Lay::TPRM});
     double rate = 0.0, scaling_sd = 1.0, scaling_multiplier = 1.0;
     uint64_t win_bits = 0;
     int win_len = 0;
@@ -73,27 +98,28 @@ __global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const Rwm
     bool dead = false;
 
     for (int i = 1; i <= a.n_iterations; ++i) {
+        const double *const pz = sh;
         const double di = (double)i;
         // ---- adaptation of covmat_proposal (adaptMCMC_source.cpp:117-139) ------------------
         bool dirty = false, use_emp = false;
         double s2 = 0.0;
-        if (ass != 0 && i >= ass && (ashs == 0 || __dmul_rn(rate, di) < (double)ashs)) {
+        if (ass != 0 && i >= ass && (ashs == 0 || mul_rn(rate, di) < (double)ashs)) {
             scaling_multiplier = exp(a.d_cool_pow[i] * (rate - 0.234));
-            scaling_sd = __dmul_rn(scaling_sd, scaling_multiplier);
+            scaling_sd = mul_rn(scaling_sd, scaling_multiplier);
             scaling_sd = (a.max_scaling_sd < scaling_sd) ? a.max_scaling_sd : scaling_sd; // std::min
-            s2 = __dmul_rn(scaling_sd, scaling_sd);
+            s2 = mul_rn(scaling_sd, scaling_sd);
             bool any_small = false;
 #pragma unroll
-            for (int k = 0; k < D; ++k) any_small |= (__dmul_rn(s2, sh.cov[tri(k, k)]) < 2E-16);
+            for (int k = 0; k < D; ++k) any_small |= (mul_rn(s2, pz[Lay::COV + tri(k, k)]) < 2E-16);
             dirty = !any_small;
-        } else if (ashs != 0 && __dmul_rn(rate, di) >= (double)ashs) {
+        } else if (ashs != 0 && mul_rn(rate, di) >= (double)ashs) {
             scaling_sd = a.shape_scaling_sd;
-            s2 = __dmul_rn(scaling_sd, scaling_sd);
+            s2 = mul_rn(scaling_sd, scaling_sd);
             dirty = true;
             use_emp = true;
         }
-        if (a.d_scaling_sd) a.d_scaling_sd[(int64_t)(i - 1) * n + c] = scaling_sd;
-        if (a.d_scaling_multiplier) a.d_scaling_multiplier[(int64_t)(i - 1) * n + c] = scaling_multiplier;
+        if (FULL && a.d_scaling_sd && live) a.d_scaling_sd[(int64_t)(i - 1) * n + c] = scaling_sd;
+        if (FULL && a.d_scaling_multiplier && live) a.d_scaling_multiplier[(int64_t)(i - 1) * n + c] = scaling_multiplier;
 
         // ---- R = chol(covmat_proposal) when it was assigned (:153) -------------------------
         if (dirty && !dead) {
@@ -101,17 +127,19 @@ __global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const Rwm
             double prod = 1.0;
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                double ajj = s2 * (use_emp ? C[tri(j, j)] : sh.cov[tri(j, j)]);
+                const double cjj = Cl[tri(j, j) * 64], pjj = pz[Lay::COV + tri(j, j)];
+                double ajj = s2 * (use_emp ? cjj : pjj);
 #pragma unroll
                 for (int m = 0; m < j; ++m) ajj -= R[tri(m, j)] * R[tri(m, j)];
                 ok = ok && (ajj > 0.0);
-                const double rjj = sqrt(ajj);
-                const double rinv = 1.0 / rjj;
+                double rjj, rinv;
+                fm_sqrt_rsq(ajj, rjj, rinv);
                 R[tri(j, j)] = rjj;
                 prod *= rjj;
 #pragma unroll
                 for (int k = j + 1; k < D; ++k) {
-                    double s = s2 * (use_emp ? C[tri(j, k)] : sh.cov[tri(j, k)]);
+                    const double cjk = Cl[tri(j, k) * 64], pjk = pz[Lay::COV + tri(j, k)];
+                    double s = s2 * (use_emp ? cjk : pjk);
 #pragma unroll
                     for (int m = 0; m < j; ++m) s -= R[tri(m, j)] * R[tri(m, k)];
                     R[tri(j, k)] = s * rinv;
@@ -130,7 +158,7 @@ __global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const Rwm
         double Y[D], prop[D];
         if (inject) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) Y[k] = a.d_Z[((int64_t)(i - 1) * D + k) * n + c];
+            for (int k = 0; k < D; ++k) Y[k] = a.d_Z[((int64_t)(i - 1) * D + k) * n + cc];
         } else {
 #pragma unroll
             for (int b = 0; 2 * b < D; ++b) {
@@ -151,61 +179,63 @@ __global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const Rwm
         }
 
         // ---- target and Metropolis-Hastings log ratio (:157-171) ----------------------------
-        const double t_prop = Target<KIND, D>::eval(prop, sh.tprm);
+        const double t_prop = Target<KIND, D>::eval(prop, PrmView{pz + Lay::TPRM});
         double la;
         if (!isfinite(t_prop)) {
             la = -__builtin_inf();
         } else {
             la = t_prop - t_cur;
-            const double p = log(rootTerm * exp(-0.5 * q)); // mvrnorm_pdf, both directions (:48-64)
-            la = __dadd_rn(la, p);
-            la = __dsub_rn(la, p);
+            const double p = fm_log<true>(rootTerm * exp(-0.5 * q)); // mvrnorm_pdf, both directions (:48-64)
+            la = add_rn(la, p);
+            la = add_rn(la, -p);
         }
 
         // ---- accept / reject (:174-182) ------------------------------------------------------
         double A;
         if (inject) {
-            A = a.d_U[(int64_t)(i - 1) * n + c];
+            A = a.d_U[(int64_t)(i - 1) * n + cc];
         } else {
             double u1;
             philox_uniform2(key, gchain, (uint32_t)i, TAG_RWM_UNIFORM, 0u, A, u1);
         }
-        const double logA = log(A);
+        const double logA = fm_log<true>(A);
         const bool accept = logA < la;
         if (accept) {
 #pragma unroll
             for (int k = 0; k < D; ++k) theta[k] = prop[k];
             t_cur = t_prop;
         }
-        if (a.d_accepted) a.d_accepted[(int64_t)(i - 1) * n + c] = accept ? 1 : 0;
-        if (a.d_log_acceptance) a.d_log_acceptance[(int64_t)(i - 1) * n + c] = la;
-        if (a.d_log_A) a.d_log_A[(int64_t)(i - 1) * n + c] = logA;
+        if (FULL && live) {
+            if (a.d_accepted) a.d_accepted[(int64_t)(i - 1) * n + c] = accept ? 1 : 0;
+            if (a.d_log_acceptance) a.d_log_acceptance[(int64_t)(i - 1) * n + c] = la;
+            if (a.d_log_A) a.d_log_A[(int64_t)(i - 1) * n + c] = logA;
+        }
 
         // ---- trace (:185) -------------------------------------------------------------------
         const bool keep = (i % a.thin) == 0;
         const int64_t t = i / a.thin - 1;
-        if (a.d_trace && keep) {
+        if (a.d_trace && keep && live) {
 #pragma unroll
             for (int k = 0; k < D; ++k) a.d_trace[(t * D + k) * n + c] = theta[k];
         }
 
-        // ---- acceptance rate (:188-207) -----------------------------------------------------
+        // ---- acceptance rate (:188-207): the reference's exact operation sequence ------------
         const double acc = accept ? 1.0 : 0.0;
         if (i == 1) {
             rate = acc;
         } else if (w == 0) {
             if (window == 0) {
-                rate = __dadd_rn(rate, __ddiv_rn(__dsub_rn(acc, rate), di));
+                rate = add_rn(rate, div_rn(add_rn(acc, -rate), di));
             } else {
                 win_bits = (win_bits << 1) | (accept ? 1ull : 0ull);
                 if (win_len < window) ++win_len;
                 const uint64_t m = (win_len >= 64) ? ~0ull : ((1ull << win_len) - 1ull);
-                rate = __ddiv_rn((double)__popcll(win_bits & m), (double)win_len);
+                rate = div_rn((double)__popcll(win_bits & m), (double)win_len);
             }
         } else {
-            rate = __dadd_rn(__dmul_rn(rate, 1 - w), __dmul_rn(acc, w));
+            rate = add_rn(mul_rn(rate, 1 - w), mul_rn(acc, w));
         }
-        if (a.d_rate_trace) a.d_rate_trace[(int64_t)(i - 1) * n + c] = rate;
+        if (FULL && a.d_rate_trace && live) a.d_rate_trace[(int64_t)(i - 1) * n + c] = rate;
 
         // ---- running mean / covariance (:210-214, update_sigma :42-45) ----------------------
         if (need_moments) {
@@ -214,41 +244,44 @@ __global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const Rwm
             const double inv_i = 1.0 / di;
             double res[D];
 #pragma unroll
-            for (int k = 0; k < D; ++k) res[k] = theta[k] - mean[k];
-#pragma unroll
-            for (int cc = 0; cc < D; ++cc) {
-#pragma unroll
-                for (int r = 0; r <= cc; ++r)
-                    C[tri(r, cc)] = (C[tri(r, cc)] * im1 + (sfac * res[r]) * res[cc]) * inv_i;
+            for (int k = 0; k < D; ++k) {
+                const double mk = Ml[k * 64];
+                res[k] = theta[k] - mk;
+                Ml[k * 64] = mk + res[k] * inv_i;
             }
+            const bool sig = FULL && a.d_sigma_trace && keep && live;
 #pragma unroll
-            for (int k = 0; k < D; ++k) mean[k] += res[k] * inv_i;
-            if (a.d_sigma_trace && keep) {
+            for (int cc2 = 0; cc2 < D; ++cc2) {
 #pragma unroll
-                for (int cc = 0; cc < D; ++cc) {
-#pragma unroll
-                    for (int r = 0; r < D; ++r)
-                        a.d_sigma_trace[(t * (D * D) + cc * D + r) * n + c] = C[r <= cc ? tri(r, cc) : tri(cc, r)];
+                for (int r = 0; r <= cc2; ++r) {
+                    const double v = (Cl[tri(r, cc2) * 64] * im1 + (sfac * res[r]) * res[cc2]) * inv_i;
+                    Cl[tri(r, cc2) * 64] = v;
+                    if (sig) {
+                        a.d_sigma_trace[(t * (D * D) + cc2 * D + r) * n + c] = v;
+                        if (r != cc2) a.d_sigma_trace[(t * (D * D) + r * D + cc2) * n + c] = v;
+                    }
                 }
             }
         }
     }
 
+    if (live) {
 #pragma unroll
-    for (int k = 0; k < D; ++k) {
-        if (a.d_final_theta) a.d_final_theta[(int64_t)k * n + c] = theta[k];
-        if (a.d_final_mean) a.d_final_mean[(int64_t)k * n + c] = mean[k];
-    }
-    if (a.d_final_cov) {
-#pragma unroll
-        for (int cc = 0; cc < D; ++cc) {
-#pragma unroll
-            for (int r = 0; r < D; ++r)
-                a.d_final_cov[(int64_t)(cc * D + r) * n + c] = C[r <= cc ? tri(r, cc) : tri(cc, r)];
+        for (int k = 0; k < D; ++k) {
+            if (a.d_final_theta) a.d_final_theta[(int64_t)k * n + c] = theta[k];
+            if (a.d_final_mean) a.d_final_mean[(int64_t)k * n + c] = Ml[k * 64];
         }
+        if (a.d_final_cov) {
+#pragma unroll
+            for (int cc2 = 0; cc2 < D; ++cc2) {
+#pragma unroll
+                for (int r = 0; r < D; ++r)
+                    a.d_final_cov[(int64_t)(cc2 * D + r) * n + c] = Cl[(r <= cc2 ? tri(r, cc2) : tri(cc2, r)) * 64];
+            }
+        }
+        if (a.d_acceptance_rate) a.d_acceptance_rate[c] = rate;
+        if (a.d_status) a.d_status[c] = status;
     }
-    if (a.d_acceptance_rate) a.d_acceptance_rate[c] = rate;
-    if (a.d_status) a.d_status[c] = status;
 }
 
 // The normals / uniforms a Philox run draws: Z [n_iterations][d][n], U [n_iterations][n].
@@ -295,23 +328,34 @@ __global__ __launch_bounds__(256) void init_normal_kernel(uint64_t seed, int64_t
 template <int D, int KIND>
 static int launch_rwm_lane_dk(const RwmArgs &a, const RwmParams &p, hipStream_t s)
 {
-    using Sh = RwmShared<D, KIND>;
-    Sh sh;
-    for (int k = 0; k < D; ++k) sh.init[k] = p.init[k];
-    for (int e = 0; e < Sh::T; ++e) {
-        sh.cov[e] = p.cov_packed[e];
-        sh.R0[e] = p.R0_packed[e];
-    }
-    sh.root0 = 1.0 / std::sqrt(a.twopi_pow_d * p.det0);
-    sh.tprm[0] = 0.0;
-    const int np = target_param_count(KIND, D);
-    if ((int)p.tparams.size() != np)
-        return set_error(MCMC_E_BAD_ARG, "target kind %d with d=%d needs %d parameters, got %d", KIND, D, np,
+    using Lay = RwmLayout<D, KIND>;
+    if ((int)p.tparams.size() != Lay::NP)
+        return set_error(MCMC_E_BAD_ARG, "target kind %d with d=%d needs %d parameters, got %d", KIND, D, Lay::NP,
                          (int)p.tparams.size());
-    for (int e = 0; e < np; ++e) sh.tprm[e] = p.tparams[e];
+    std::vector<double> blob(Lay::TOTAL, 0.0);
+    for (int k = 0; k < D; ++k) blob[Lay::INIT + k] = p.init[k];
+    for (int e = 0; e < Lay::T; ++e) {
+        blob[Lay::COV + e] = p.cov_packed[e];
+        blob[Lay::R0 + e] = p.R0_packed[e];
+    }
+    blob[Lay::ROOT0] = 1.0 / std::sqrt(a.twopi_pow_d * p.det0);
+    for (int e = 0; e < Lay::NP; ++e) blob[Lay::TPRM + e] = p.tparams[e];
+    double *d_prm = nullptr;
+    MCMC_HIP_CHECK(hipMallocAsync((void **)&d_prm, blob.size() * sizeof(double), s));
+    MCMC_HIP_CHECK(hipMemcpyAsync(d_prm, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    MCMC_HIP_CHECK(hipStreamSynchronize(s)); // blob is a local: do not let the copy outlive it
     const int64_t grid = (a.n_chains + 63) / 64;
-    hipLaunchKernelGGL((rwm_lane_kernel<D, KIND>), dim3((unsigned)grid), dim3(64), 0, s, a, sh);
-    MCMC_HIP_CHECK(hipGetLastError());
+    const size_t ldsb = (size_t)Lay::LDS_DOUBLES * sizeof(double);
+    const bool full = a.d_Z || a.d_sigma_trace || a.d_accepted || a.d_log_acceptance || a.d_log_A || a.d_scaling_sd ||
+                      a.d_scaling_multiplier || a.d_rate_trace;
+    if (full)
+        hipLaunchKernelGGL((rwm_lane_kernel<D, KIND, true>), dim3((unsigned)grid), dim3(64), ldsb, s, a, (const double *)d_prm);
+    else
+        hipLaunchKernelGGL((rwm_lane_kernel<D, KIND, false>), dim3((unsigned)grid), dim3(64), ldsb, s, a, (const double *)d_prm);
+    hipError_t e1 = hipGetLastError();
+    hipError_t e2 = hipFreeAsync(d_prm, s);
+    if (e1 != hipSuccess) return set_error(MCMC_E_HIP, "rwm_lane_kernel launch failed: %s", hipGetErrorString(e1));
+    if (e2 != hipSuccess) return set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e2));
     return MCMC_OK;
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/mcmc_amd.h"
+#include "fastmath.h"
 
 namespace mcmc {
 
@@ -53,7 +54,7 @@ struct Target<MCMC_TARGET_GOLDSTEIN_PRICE, 2> {
         const double fact2a = t * t;
         const double fact2b = 18 - 32 * x1 + 12 * (x1 * x1) + 48 * x2 - 36 * x1 * x2 + 27 * (x2 * x2);
         const double fact2 = 30 + fact2a * fact2b;
-        return -log(fact1 * fact2);
+        return -fm_log<true>(fact1 * fact2);
     }
 };
 

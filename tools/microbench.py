@@ -1,0 +1,65 @@
+"""Development microbenchmarks (GPU): times the batch kernels with HIP events."""
+import argparse, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import mcmc_amd
+
+
+def timeit(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    return min(ts)
+
+
+def gibbs(d, chains, sweeps, trace=True, rho=0.5):
+    idx = np.arange(d)
+    sigma = rho ** np.abs(idx[:, None] - idx[None, :])
+    out = {}
+    if trace:
+        out["trace"] = torch.empty((sweeps, d, chains), dtype=torch.float64, device="cuda")
+    f = lambda: mcmc_amd.tmvn_gibbs_batch(chains, sweeps, np.zeros(d), sigma, np.full(d, -1.0), np.full(d, 2.0), np.zeros(d),
+                                          seed=2, trace=trace, out=out)
+    ms = timeit(f)
+    rate = chains * sweeps / (ms * 1e-3)
+    print(f"gibbs d={d} chains={chains} sweeps={sweeps} trace={trace}: {ms:.2f} ms  {rate:.3e} chain-sweeps/s  "
+          f"{rate*d*(2*d+142)/1e12:.2f} TF alg  cycles/coord/wave={ms*1e-3*2.4e9*1024/ (chains/64*sweeps*d):.0f} (if 1024 SIMDs busy)")
+
+
+def rwm(d, chains, iters, trace=True):
+    idx = np.arange(d)
+    Sig = 0.9 ** np.abs(idx[:, None] - idx[None, :])
+    H = np.linalg.inv(Sig); H = 0.5 * (H + H.T)
+    tgt = mcmc_amd.Target.gaussian(np.zeros(d), H)
+    init = mcmc_amd.init_normal(1, chains, np.zeros(d), 2.0)
+    out = {}
+    if trace:
+        out["theta_trace"] = torch.empty((iters, d, chains), dtype=torch.float64, device="cuda")
+    f = lambda: mcmc_amd.adapt_rwm_batch(tgt, chains, init, np.eye(d), iters, 100, 0.0, 0, 500, seed=1, trace=trace, out=out)
+    ms = timeit(f)
+    rate = chains * iters / (ms * 1e-3)
+    print(f"rwm d={d} chains={chains} iters={iters} trace={trace}: {ms:.2f} ms  {rate:.3e} chain-iter/s  "
+          f"cycles/iter/wave={ms*1e-3*2.4e9/iters/max(1,chains/64/1024):.0f}")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="*", default=["gibbs", "rwm"])
+    args = ap.parse_args()
+    if "gibbs" in args.what:
+        gibbs(10, 1 << 20, 200)
+        gibbs(10, 1 << 20, 200, trace=False)
+        gibbs(10, 1 << 16, 400)
+        gibbs(4, 1 << 20, 200)
+        gibbs(32, 1 << 18, 50)
+        gibbs(128, 1 << 17, 10, trace=False)
+    if "rwm" in args.what:
+        rwm(10, 1 << 16, 2000)
+        rwm(10, 1 << 16, 2000, trace=False)
+        rwm(10, 1 << 18, 1000)
+        rwm(4, 1 << 18, 2000)
+        rwm(2, 1 << 18, 2000)
