@@ -1,0 +1,144 @@
+"""CPU suite: the C-ABI library loads, exports every symbol include/mcmc_amd.h declares, its
+structs match the ctypes mirror, and the host-side logic (validation, index helpers, the shared
+Gibbs precompute) works without a GPU.  No compute entry point is exercised here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mcmc_amd.h")
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mcmc_[A-Za-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mcmc_amd import _lib
+
+    names = _declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(_lib.lib, n), f"{n} is declared in include/mcmc_amd.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes SIGNATURES and the header disagree"
+    assert _lib.lib.mcmc_amd_abi_version() == 1
+    assert _lib.lib.mcmc_amd_max_lane_dim() >= 10 and _lib.lib.mcmc_amd_max_dim() >= 128
+
+
+def test_header_compiles_as_c_and_struct_layout_matches_ctypes(tmp_path):
+    from mcmc_amd import _lib
+
+    prog = tmp_path / "layout.c"
+    prog.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "mcmc_amd.h"\n'
+        "int main(void){\n"
+        'printf("%zu %zu %zu %zu %zu\\n", sizeof(mcmc_target), sizeof(mcmc_rwm_config), sizeof(mcmc_rwm_io),'
+        " sizeof(mcmc_gibbs_config), sizeof(mcmc_gibbs_io));\n"
+        'printf("%zu %zu %zu %zu\\n", offsetof(mcmc_rwm_config, seed), offsetof(mcmc_rwm_io, d_status),'
+        " offsetof(mcmc_gibbs_config, seed), offsetof(mcmc_gibbs_io, d_status));\n"
+        "return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    sizes = [C.sizeof(_lib.McmcTarget), C.sizeof(_lib.RwmConfig), C.sizeof(_lib.RwmIO), C.sizeof(_lib.GibbsConfig),
+             C.sizeof(_lib.GibbsIO)]
+    offs = [_lib.RwmConfig.seed.offset, _lib.RwmIO.d_status.offset, _lib.GibbsConfig.seed.offset,
+            _lib.GibbsIO.d_status.offset]
+    assert [int(x) for x in out] == sizes + offs
+
+
+def test_index_helpers_follow_the_reference(oracle):
+    """sub1 / sub2 / negSubCol / negSubRow (tmvrnormGibbs.cpp:12-37) are host copies in the library."""
+    import mcmc_amd
+
+    x = np.random.default_rng(0).standard_normal((5, 5))
+    for i in range(5):
+        np.testing.assert_array_equal(mcmc_amd.sub1(x, i), np.delete(np.delete(x, i, 0), i, 1))
+        np.testing.assert_array_equal(mcmc_amd.sub1(x, i), oracle.sub1(x, i))
+        np.testing.assert_array_equal(mcmc_amd.sub2(x, i, (i + 2) % 5), oracle.sub2(x, i, (i + 2) % 5))
+        np.testing.assert_array_equal(mcmc_amd.negSubCol(x[:, 0], i), np.delete(x[:, 0], i))
+        np.testing.assert_array_equal(mcmc_amd.negSubRow(x[0], i), np.delete(x[0], i))
+    assert mcmc_amd.sub2(x, 1, 1).shape == (1, 4)  # a 1 x (d-1) matrix, as arma::mat x.row(a)
+    with pytest.raises(mcmc_amd.McmcError):
+        mcmc_amd.sub1(x, 5)
+    with pytest.raises(mcmc_amd.McmcError):
+        mcmc_amd.negSubCol(x[0], -1)
+
+
+def test_gibbs_precompute_from_precision_matches_reference_partitioning(oracle):
+    import mcmc_amd
+
+    rng = np.random.default_rng(5)
+    for d in (1, 2, 5, 10, 33, 128):
+        A = rng.standard_normal((d, d))
+        sigma = A @ A.T / d + np.eye(d)
+        P, sd = mcmc_amd.tmvn_precompute(sigma)
+        st, Po, sdo = oracle.tmvn_precompute(sigma)
+        assert st == 0 and P.shape == (d, d - 1)
+        np.testing.assert_allclose(P, Po, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(sd, sdo, rtol=1e-13)
+    with pytest.raises(mcmc_amd.McmcError) as e:
+        mcmc_amd.tmvn_precompute(np.array([[1.0, 2.0], [2.0, 1.0]]))
+    assert e.value.code == -4
+
+
+def test_validation_happens_before_any_gpu_work():
+    """Bad arguments are refused on the host (the reference has no validation)."""
+    from mcmc_amd import _lib
+    from mcmc_amd._lib import lib
+
+    d = 2
+    init = (C.c_double * d)(0.0, 0.0)
+    cov = (C.c_double * 4)(1.0, 0.5, 0.2, 1.0)  # asymmetric
+    prm = (C.c_double * 6)(0, 0, 1, 0, 0, 1)
+    tgt = _lib.McmcTarget(_lib.MCMC_TARGET_GAUSSIAN_PREC, 6, prm)
+    cfg = _lib.RwmConfig(d=d, n_iterations=10, n_chains=4, thin=1, rng_mode=0)
+    io = _lib.RwmIO()
+    io.h_init_theta = init
+    io.h_covmat = cov
+    assert lib.mcmc_adapt_rwm_batch(C.byref(tgt), C.byref(cfg), C.byref(io), None) == _lib.MCMC_E_BAD_ARG
+    assert b"symmetric" in lib.mcmc_amd_last_error()
+    cov2 = (C.c_double * 4)(1.0, 2.0, 2.0, 1.0)  # not positive definite
+    io.h_covmat = cov2
+    assert lib.mcmc_adapt_rwm_batch(C.byref(tgt), C.byref(cfg), C.byref(io), None) == _lib.MCMC_E_NOT_PD
+    cfg.acceptance_window = 65
+    assert lib.mcmc_adapt_rwm_batch(C.byref(tgt), C.byref(cfg), C.byref(io), None) == _lib.MCMC_E_UNSUPPORTED
+    cfg.acceptance_window = 0
+    cfg.thin = 0
+    assert lib.mcmc_adapt_rwm_batch(C.byref(tgt), C.byref(cfg), C.byref(io), None) == _lib.MCMC_E_BAD_ARG
+    assert lib.mcmc_adapt_rwm_batch(None, C.byref(cfg), C.byref(io), None) == _lib.MCMC_E_BAD_ARG
+    gcfg = _lib.GibbsConfig(d=2, n_sweeps=0, n_chains=1, thin=1)
+    assert lib.mcmc_tmvn_gibbs_batch(C.byref(gcfg), C.byref(_lib.GibbsIO()), None) == _lib.MCMC_E_BAD_ARG
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under mcmc_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "mcmc_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".c")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                for pat in ("liboracle", "mcmc_oracle", "from oracle", "import oracle", "oracle/", "orc_"):
+                    assert pat not in txt, f"{f} references the oracle ({pat})"
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """Importing the package without libmcmc_amd.so must raise, not fall back to the CPU."""
+    code = (
+        "import importlib.util, sys, os\n"
+        f"src = os.path.join({ROOT!r}, 'mcmc_amd', '_lib.py')\n"
+        f"dst = os.path.join({str(tmp_path)!r}, '_lib.py')\n"
+        "open(dst, 'w').write(open(src).read())\n"
+        "spec = importlib.util.spec_from_file_location('_lib_copy', dst)\n"
+        "m = importlib.util.module_from_spec(spec)\n"
+        "try:\n    spec.loader.exec_module(m)\nexcept ImportError as e:\n    print('IMPORTERROR', e); sys.exit(0)\n"
+        "sys.exit(1)\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0 and "IMPORTERROR" in r.stdout and "no CPU fallback" in r.stdout

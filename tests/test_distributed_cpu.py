@@ -1,0 +1,86 @@
+"""CPU suite: the N>1 path -- chain sharding and the single all-reduce of moment sums -- with two
+gloo ranks.  On GPUs the same code runs over RCCL (backend "nccl"); the per-rank partial sums come
+from mcmc_rhat_partial, whose contract (sum m, sum m^2, sum s^2, count) is reproduced here in numpy."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _partial(mean, var):
+    d = mean.shape[0]
+    out = np.empty(3 * d + 1)
+    out[:d], out[d:2 * d], out[2 * d:3 * d], out[3 * d] = mean.sum(1), (mean ** 2).sum(1), var.sum(1), mean.shape[1]
+    return out
+
+
+def _worker(rank, world, port, total_chains, n_per_chain, d, q):
+    import torch
+    import torch.distributed as dist
+
+    from mcmc_amd.diagnostics import rhat_from_partial
+    from mcmc_amd.sharding import all_reduce_sum, shard_chains
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    off, cnt = shard_chains(total_chains, rank, world)
+    rng = np.random.default_rng(123)
+    draws = rng.standard_normal((n_per_chain, d, total_chains)) + 0.3 * rng.standard_normal((1, d, total_chains))
+    mine = draws[:, :, off:off + cnt]
+    part = torch.tensor(_partial(mine.mean(0), mine.var(0, ddof=1)))
+    all_reduce_sum(part)
+    q.put((rank, off, cnt, rhat_from_partial(part, n_per_chain)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_rhat_equals_single_process():
+    import torch.multiprocessing as mp
+
+    from mcmc_amd.diagnostics import rhat_from_partial
+
+    total, n, d, world = 37, 200, 3, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, n, d, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [(r[1], r[2]) for r in res] == [(0, 19), (19, 18)]  # contiguous, balanced, covers [0, 37)
+    rng = np.random.default_rng(123)
+    draws = rng.standard_normal((n, d, total)) + 0.3 * rng.standard_normal((1, d, total))
+    want = rhat_from_partial(_partial(draws.mean(0), draws.var(0, ddof=1)), n)
+    # textbook Gelman-Rubin on the pooled chains
+    m, s2 = draws.mean(0), draws.var(0, ddof=1)
+    W, B_over_n = s2.mean(1), m.var(1, ddof=1)
+    np.testing.assert_allclose(want, np.sqrt(((n - 1) / n * W + B_over_n) / W), rtol=1e-12)
+    for r in res:
+        np.testing.assert_allclose(r[3], want, rtol=1e-12)
+    assert np.all(want > 1.02)  # the injected between-chain offsets are detected
+
+
+def test_shard_chains_properties():
+    from mcmc_amd.sharding import shard_chains
+
+    for total in (0, 1, 7, 64, 65536, 1_048_576 + 3):
+        for world in (1, 2, 3, 8):
+            parts = [shard_chains(total, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and sum(c for _, c in parts) == total
+            for (o1, c1), (o2, _) in zip(parts, parts[1:]):
+                assert o1 + c1 == o2
+            assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+    with pytest.raises(ValueError):
+        shard_chains(10, 2, 2)
