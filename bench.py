@@ -36,6 +36,25 @@ def rwm_flops_per_iter(d, with_chol):
     return f + (d ** 3) / 3.0 if with_chol else f
 
 
+def pmc_traffic_bytes(n_chains, n_iter, d):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r1_c2_pmc.csv), for the
+    default C2 shape only: WRITE_SIZE + 2 x FETCH_SIZE (KiB; the x2 is the gfx950 FETCH_SIZE correction of
+    MI355X_MICROARCH.md).  bench.py cannot collect PMC counters itself, so other shapes report null."""
+    path = os.path.join(ROOT, "profiles", "r1_c2_pmc.csv")
+    if (n_chains, n_iter, d) != (65536, 10000, 10) or not os.path.exists(path):
+        return None
+    vals = {}
+    for line in open(path):
+        if line.startswith("#") or "," not in line:
+            continue
+        k, v = line.strip().split(",")
+        if k != "counter":
+            vals[k] = float(v)
+    if "WRITE_SIZE" not in vals or "FETCH_SIZE" not in vals:
+        return None
+    return (vals["WRITE_SIZE"] + 2.0 * vals["FETCH_SIZE"]) * 1024.0
+
+
 def c2_problem(d=10, rho=0.9):
     idx = np.arange(d)
     Sig = rho ** np.abs(idx[:, None] - idx[None, :])
@@ -169,7 +188,8 @@ def main():
                                    f"{n_chains} chains/GPU x {n_iter} iterations, adapt 100/500, full trace to HBM",
                        "chains_per_gpu": n_chains, "iterations": n_iter, "d": d, "parallelism": f"chains sharded x{world}"},
             "roofline": {"bound": "fp64-valu", "achieved": achieved_tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tf / FP64_VALU_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved_tf / FP64_VALU_PEAK_TFLOPS, "traffic": pmc_traffic_bytes(n_chains, n_iter, d),
+                         "algorithmic_bytes": bytes_launch,
                          "kernel": f"rwm_lane_kernel<{d},gaussian>", "kernel_ms": kern_ms,
                          "flops_per_chain_iteration": rwm_flops_per_iter(d, True),
                          "hbm_write_GBs": bytes_launch / (kern_ms * 1e-3) / 1e9,
