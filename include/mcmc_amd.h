@@ -56,6 +56,12 @@ extern "C" {
 #define MCMC_RNG_PHILOX 0
 #define MCMC_RNG_INJECTED 1
 
+/* ----- kernel choice for the Metropolis path ----------------------------------------- */
+#define MCMC_KERNEL_AUTO 0   /* one chain per lane for d <= mcmc_amd_max_lane_dim(), else per workgroup */
+#define MCMC_KERNEL_LANE 1   /* one chain per lane (register-resident state), d <= 12               */
+#define MCMC_KERNEL_BLOCK 2  /* one chain per 256-thread workgroup (LDS-resident factor), d <= 128,
+                                Gaussian target only                                               */
+
 /* ----- target log-densities --------------------------------------------------------- */
 /*
  * Replaces the R closure `target` of adaptMCMC / rwMCMC (adaptMCMC_source.cpp:75,97,158;
@@ -74,7 +80,7 @@ typedef struct mcmc_target {
 /* ----- library ----------------------------------------------------------------------- */
 int mcmc_amd_abi_version(void);
 const char *mcmc_amd_last_error(void);
-/* largest d served by the one-chain-per-lane kernels; above it the per-wavefront kernels run */
+/* largest d served by the one-chain-per-lane Metropolis kernel; above it the per-workgroup kernel runs */
 int mcmc_amd_max_lane_dim(void);
 int mcmc_amd_max_dim(void);
 
@@ -101,7 +107,7 @@ typedef struct mcmc_rwm_config {
     double max_scaling_sd;         /* reference default 50.0                                 */
     uint64_t seed;                 /* Philox key                                             */
     int32_t rng_mode;              /* MCMC_RNG_PHILOX | MCMC_RNG_INJECTED                     */
-    int32_t reserved;
+    int32_t kernel;                /* MCMC_KERNEL_AUTO (0) | MCMC_KERNEL_LANE | MCMC_KERNEL_BLOCK: which device kernel runs */
 } mcmc_rwm_config;
 
 typedef struct mcmc_rwm_io {

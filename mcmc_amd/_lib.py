@@ -24,6 +24,10 @@ MCMC_CHAIN_NONFINITE_STATE = 2
 MCMC_RNG_PHILOX = 0
 MCMC_RNG_INJECTED = 1
 
+MCMC_KERNEL_AUTO = 0
+MCMC_KERNEL_LANE = 1
+MCMC_KERNEL_BLOCK = 2
+
 MCMC_TARGET_GAUSSIAN_PREC = 0
 MCMC_TARGET_GOLDSTEIN_PRICE = 1
 MCMC_TARGET_BANANA = 2
@@ -45,7 +49,7 @@ class RwmConfig(C.Structure):
         ("acceptance_window", C.c_int32), ("thin", C.c_int32),
         ("acceptance_rate_weight", C.c_double), ("adapt_size_cooling", C.c_double),
         ("max_scaling_sd", C.c_double),
-        ("seed", C.c_uint64), ("rng_mode", C.c_int32), ("reserved", C.c_int32),
+        ("seed", C.c_uint64), ("rng_mode", C.c_int32), ("kernel", C.c_int32),
     ]
 
 

@@ -249,7 +249,8 @@ def _stream_ptr():
 def adapt_rwm_batch(target, n_chains, init_theta, covmat, n_iterations, adapt_size_start=0,
                     acceptance_rate_weight=0.0, acceptance_window=0, adapt_shape_start=0, *, seed=0,
                     adapt_size_cooling=0.99, max_scaling_sd=50.0, thin=1, chain_offset=0, Z=None, U=None,
-                    trace=True, sigma_trace=False, final=True, diagnostics=False, out=None, device="cuda"):
+                    trace=True, sigma_trace=False, final=True, diagnostics=False, out=None, device="cuda",
+                    kernel="auto"):
     """Many independent adaptMCMC chains in one launch (adaptMCMC_source.cpp:75-219 per chain).
 
     init_theta: length-d vector shared by all chains, or a [d, n_chains] CUDA tensor.
@@ -258,7 +259,8 @@ def adapt_rwm_batch(target, n_chains, init_theta, covmat, n_iterations, adapt_si
     [n_chains], status [n_chains], final_theta / final_mean [d, n_chains], final_cov
     [d*d, n_chains], and with diagnostics=True accepted / log_acceptance / log_A /
     scaling_sd / scaling_multiplier / rate_trace, each [n_iterations, n_chains].
-    `out` may carry preallocated tensors under the same keys.
+    `out` may carry preallocated tensors under the same keys.  kernel = "auto" | "lane" | "block"
+    picks the device kernel (auto: per lane for d <= 12, per 256-thread workgroup above).
     """
     torch = _torch()
     t = _need_target(target)
@@ -293,7 +295,8 @@ def adapt_rwm_batch(target, n_chains, init_theta, covmat, n_iterations, adapt_si
                       acceptance_rate_weight=float(acceptance_rate_weight),
                       adapt_size_cooling=float(adapt_size_cooling), max_scaling_sd=float(max_scaling_sd),
                       seed=int(seed) & 0xFFFFFFFFFFFFFFFF,
-                      rng_mode=L.MCMC_RNG_INJECTED if Z is not None else L.MCMC_RNG_PHILOX, reserved=0)
+                      rng_mode=L.MCMC_RNG_INJECTED if Z is not None else L.MCMC_RNG_PHILOX,
+                      kernel={"auto": L.MCMC_KERNEL_AUTO, "lane": L.MCMC_KERNEL_LANE, "block": L.MCMC_KERNEL_BLOCK}[kernel])
     if (Z is None) != (U is None):
         raise ValueError("give both Z and U, or neither")
     if Z is not None:

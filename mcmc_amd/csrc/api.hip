@@ -111,7 +111,7 @@ using namespace mcmc;
 extern "C" int mcmc_amd_abi_version(void) { return MCMC_AMD_ABI_VERSION; }
 extern "C" const char *mcmc_amd_last_error(void) { return g_last_error.c_str(); }
 extern "C" int mcmc_amd_max_lane_dim(void) { return kMaxLaneDimRwm; }
-extern "C" int mcmc_amd_max_dim(void) { return kMaxDimGibbs; }
+extern "C" int mcmc_amd_max_dim(void) { return kMaxDimRwm; }
 
 // ============================================================================================
 extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_config *cfg, const mcmc_rwm_io *io,
@@ -138,8 +138,14 @@ extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_co
     } else if (cfg->rng_mode != MCMC_RNG_PHILOX) {
         return set_error(MCMC_E_BAD_ARG, "unknown rng_mode %d", cfg->rng_mode);
     }
-    if (d > kMaxLaneDimRwm)
-        return set_error(MCMC_E_UNSUPPORTED, "adaptive RWM: d=%d above the lane-kernel limit %d", d, kMaxLaneDimRwm);
+    if (d > kMaxDimRwm) return set_error(MCMC_E_UNSUPPORTED, "adaptive RWM: d=%d above the limit %d", d, kMaxDimRwm);
+    if (cfg->kernel < MCMC_KERNEL_AUTO || cfg->kernel > MCMC_KERNEL_BLOCK)
+        return set_error(MCMC_E_BAD_ARG, "unknown kernel choice %d", cfg->kernel);
+    if (cfg->kernel == MCMC_KERNEL_LANE && d > kMaxLaneDimRwm)
+        return set_error(MCMC_E_UNSUPPORTED, "one-chain-per-lane kernel: d=%d above its limit %d", d, kMaxLaneDimRwm);
+    const bool use_block = cfg->kernel == MCMC_KERNEL_BLOCK || (cfg->kernel == MCMC_KERNEL_AUTO && d > kMaxLaneDimRwm);
+    if (use_block && target->kind != MCMC_TARGET_GAUSSIAN_PREC)
+        return set_error(MCMC_E_UNSUPPORTED, "the per-workgroup kernel serves the Gaussian target only");
 
     RwmParams p;
     int rc = build_rwm_params(target, d, io->h_init_theta, io->h_covmat, p);
@@ -189,7 +195,7 @@ extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_co
         MCMC_HIP_CHECK(hipStreamSynchronize(s)); // `cool` is a local: do not let the copy outlive it
         a.d_cool_pow = d_cool;
     }
-    rc = launch_rwm_lane(a, p, s);
+    rc = use_block ? launch_rwm_block(a, p, s) : launch_rwm_lane(a, p, s);
     if (d_cool) {
         hipError_t e = hipFreeAsync(d_cool, s);
         if (rc == MCMC_OK && e != hipSuccess) rc = set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e));

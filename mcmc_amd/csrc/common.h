@@ -103,6 +103,7 @@ struct RwmParams {
 };
 
 int launch_rwm_lane(const RwmArgs &a, const RwmParams &p, hipStream_t s);
+int launch_rwm_block(const RwmArgs &a, const RwmParams &p, hipStream_t s);
 int launch_rwm_streams(uint64_t seed, int64_t chain_offset, int64_t n_chains, int32_t n_iterations,
                        int32_t d, double *d_Z, double *d_U, hipStream_t s);
 int launch_init_normal(uint64_t seed, int64_t chain_offset, int64_t n_chains, int32_t d,

@@ -1,0 +1,353 @@
+// Adaptive random-walk Metropolis for 12 < d <= 128: one chain per 256-thread workgroup (gfx950).
+//
+// Replaces the main loop of adaptMCMC / rwMCMC (adaptMCMC_source.cpp:108-216, :252-313) where the
+// per-chain state no longer fits one lane: at d = 100 the packed Cholesky factor and the packed
+// empirical covariance are 40 KB each.
+//
+// Data placement per chain (= per workgroup of four wavefronts, one per SIMD of a CU):
+//   * R, the upper Cholesky factor of covmat_proposal, packed by columns, in LDS (T = d(d+1)/2
+//     doubles) together with theta, theta_mean, the normals Y, the proposal and two scratch vectors:
+//     45 KB at d = 100, so three chains share the 160 KB of a CU (12 waves, 3 per SIMD);
+//   * covmat_empirical in REGISTERS, packed element e of thread t at slot q with e = 256 q + t
+//     (<= 33 slots at d = 128).  It is only ever touched element-wise (the rank-1 update_sigma and
+//     the copy s^2 * C -> LDS that feeds the factorization), so no thread needs another's slice;
+//   * shared parameters (covmat, chol(covmat), target mean and precision) stay in HBM/L2 and are
+//     read coalesced (the precision matrix column-major, thread i reading row i).
+// Scalars of the chain (acceptance rate, scaling_sd, cached target value, ...) are replicated in
+// every thread, so decisions are taken without a broadcast.
+//
+// The factorization is the right-looking (outer-product) Cholesky in place in LDS, threads arranged
+// 16 x 16 over the trailing matrix.  It is the same arithmetic as the reference's dpotrf per element
+// but in a different summation order than the one-lane kernel; FP64 MFMA blocking is the planned
+// replacement.
+#include "common.h"
+#include "philox.h"
+#include "targets.h"
+
+namespace mcmc {
+
+constexpr int kBlockThreads = 256;
+constexpr int kBlockSlots = (kMaxDimRwm * (kMaxDimRwm + 1) / 2 + kBlockThreads - 1) / kBlockThreads; // 33
+
+// parameter block (doubles): init[d] cov[T] R0[T] root0 tmean[d] H[d*d]
+struct BlockLayout {
+    int d, T;
+    __host__ __device__ explicit BlockLayout(int d_) : d(d_), T(d_ * (d_ + 1) / 2) {}
+    __host__ __device__ int init() const { return 0; }
+    __host__ __device__ int cov() const { return d; }
+    __host__ __device__ int r0() const { return d + T; }
+    __host__ __device__ int root0() const { return d + 2 * T; }
+    __host__ __device__ int tmean() const { return d + 2 * T + 1; }
+    __host__ __device__ int H() const { return 2 * d + 2 * T + 1; }
+    __host__ __device__ int total() const { return 2 * d + 2 * T + 1 + d * d; }
+    __host__ __device__ int lds_doubles() const { return T + 6 * d + 8; }
+};
+
+template <bool FULL>
+__global__ __launch_bounds__(kBlockThreads) void rwm_block_kernel(const RwmArgs a, const double *__restrict__ prm)
+{
+    extern __shared__ double lds[];
+    const int d = a.d;
+    const BlockLayout L(d);
+    const int T = L.T;
+    const int tid = threadIdx.x;
+    double *const A = lds;        // packed upper factor R, (r,c) r<=c at c(c+1)/2 + r
+    double *const th = A + T;     // theta_current
+    double *const mn = th + d;    // theta_mean
+    double *const Y = mn + d;     // proposal normals
+    double *const pr = Y + d;     // theta_propose
+    double *const v = pr + d;     // scratch: x - mean of the target, residual
+    double *const w = v + d;      // scratch: v_i * (H v)_i
+    double *const sc = w + d;     // sc[0] = log(A)
+    const int64_t c = blockIdx.x;
+    const int64_t n = a.n_chains;
+    const uint64_t gchain = (uint64_t)(a.chain_offset + c);
+    const PhiloxKey key(a.seed);
+    const bool inject = FULL && a.d_Z != nullptr;
+    const int ass = a.adapt_size_start, ashs = a.adapt_shape_start;
+    const int window = a.acceptance_window;
+    const double wgt = a.acceptance_rate_weight;
+    const bool need_moments = ashs != 0 || (FULL && a.d_sigma_trace) || a.d_final_mean || a.d_final_cov;
+    const double *__restrict__ tmean = prm + L.tmean();
+    const double *__restrict__ H = prm + L.H();
+    const int ti = tid & 15, tk = tid >> 4;
+
+    // covmat_empirical slice in registers + the (row, col) of every slot
+    double C[kBlockSlots];
+    int rc[kBlockSlots];
+#pragma unroll
+    for (int q = 0; q < kBlockSlots; ++q) {
+        C[q] = 0.0;
+        const int e = q * kBlockThreads + tid;
+        int col = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+        while ((col + 1) * (col + 2) / 2 <= e) ++col;
+        while (col * (col + 1) / 2 > e) --col;
+        rc[q] = (e < T) ? ((e - col * (col + 1) / 2) | (col << 8)) : -1;
+    }
+    for (int e = tid; e < T; e += kBlockThreads) A[e] = prm[L.r0() + e];
+    if (tid < d) {
+        const double x0 = a.d_init ? a.d_init[(int64_t)tid * n + c] : prm[L.init() + tid];
+        th[tid] = x0;
+        mn[tid] = x0;
+    }
+    __syncthreads();
+
+    // -0.5 (x - m)^T H (x - m), rows summed in the oracle's order; result replicated in every thread
+    auto target = [&](const double *x) -> double {
+        if (tid < d) v[tid] = x[tid] - tmean[tid];
+        __syncthreads();
+        if (tid < d) {
+            double s = 0.0;
+            for (int j = 0; j < d; ++j) s += H[(int64_t)j * d + tid] * v[j];
+            w[tid] = mul_rn(v[tid], s);
+        }
+        __syncthreads();
+        double q = 0.0;
+        for (int i = 0; i < d; ++i) q = add_rn(q, w[i]);
+        return -0.5 * q;
+    };
+
+    double rootTerm = prm[L.root0()];
+    double t_cur = target(th);
+    double rate = 0.0, scaling_sd = 1.0, scaling_multiplier = 1.0;
+    uint64_t win_bits = 0;
+    int win_len = 0;
+    int32_t status = MCMC_CHAIN_OK;
+    bool dead = false;
+
+    for (int i = 1; i <= a.n_iterations; ++i) {
+        const double di = (double)i;
+        // ---- adaptation of covmat_proposal (adaptMCMC_source.cpp:117-139), replicated ---------------
+        bool dirty = false, use_emp = false;
+        double s2 = 0.0;
+        if (ass != 0 && i >= ass && (ashs == 0 || mul_rn(rate, di) < (double)ashs)) {
+            scaling_multiplier = exp(a.d_cool_pow[i] * (rate - 0.234));
+            scaling_sd = mul_rn(scaling_sd, scaling_multiplier);
+            scaling_sd = (a.max_scaling_sd < scaling_sd) ? a.max_scaling_sd : scaling_sd;
+            s2 = mul_rn(scaling_sd, scaling_sd);
+            bool any_small = false;
+            for (int k = 0; k < d; ++k) any_small |= (mul_rn(s2, prm[L.cov() + tri(k, k)]) < 2E-16);
+            dirty = !any_small;
+        } else if (ashs != 0 && mul_rn(rate, di) >= (double)ashs) {
+            scaling_sd = a.shape_scaling_sd;
+            s2 = mul_rn(scaling_sd, scaling_sd);
+            dirty = true;
+            use_emp = true;
+        }
+        if (FULL && tid == 0) {
+            if (a.d_scaling_sd) a.d_scaling_sd[(int64_t)(i - 1) * n + c] = scaling_sd;
+            if (a.d_scaling_multiplier) a.d_scaling_multiplier[(int64_t)(i - 1) * n + c] = scaling_multiplier;
+        }
+
+        // ---- R = chol(covmat_proposal) when it was assigned (:153) --------------------------------
+        if (dirty && !dead) { // uniform over the workgroup
+            if (use_emp) {
+#pragma unroll
+                for (int q = 0; q < kBlockSlots; ++q)
+                    if (rc[q] >= 0) A[q * kBlockThreads + tid] = s2 * C[q];
+            } else {
+                for (int e = tid; e < T; e += kBlockThreads) A[e] = s2 * prm[L.cov() + e];
+            }
+            __syncthreads();
+            bool ok = true;
+            double prod = 1.0;
+            for (int j = 0; j < d; ++j) {
+                const double ajj = A[tri(j, j)];
+                ok = ok && (ajj > 0.0);
+                double rjj, rinv;
+                fm_sqrt_rsq(ajj, rjj, rinv);
+                prod *= rjj;
+                for (int k = j + 1 + tid; k < d; k += kBlockThreads) A[tri(j, k)] *= rinv; // row j of R
+                __syncthreads();
+                if (tid == 0) A[tri(j, j)] = rjj;
+                // trailing update A(i,k) -= R(j,i) R(j,k), j < i <= k, threads 16 x 16 over (i, k)
+                const int m = d - 1 - j;
+                for (int ib = 0; ib * 16 < m; ++ib) {
+                    const int ii = j + 1 + ib * 16 + ti;
+                    const double rji = (ii < d) ? A[tri(j, ii)] : 0.0;
+                    for (int kb = ib; kb * 16 < m; ++kb) {
+                        const int kk = j + 1 + kb * 16 + tk;
+                        if (ii <= kk && kk < d) A[tri(ii, kk)] -= rji * A[tri(j, kk)];
+                    }
+                }
+                __syncthreads();
+            }
+            rootTerm = 1.0 / sqrt(a.twopi_pow_d * (prod * prod));
+            if (!ok) { // arma::chol throws here; the chain stops and reports where
+                dead = true;
+                status = (i << 4) | MCMC_CHAIN_CHOL_FAILED;
+                if (tid < d) th[tid] = __builtin_nan("");
+                __syncthreads();
+            }
+        }
+
+        // ---- draws: d normals, then one uniform (:149-152,174) ----------------------------------------
+        if (inject) {
+            if (tid < d) Y[tid] = a.d_Z[((int64_t)(i - 1) * d + tid) * n + c];
+            if (tid == 0) sc[0] = fm_log<true>(a.d_U[(int64_t)(i - 1) * n + c]);
+        } else {
+            const int nb = (d + 1) / 2;
+            if (tid < nb) {
+                double z0, z1;
+                philox_normal2(key, gchain, (uint32_t)i, TAG_RWM_NORMAL, (uint32_t)tid, z0, z1);
+                Y[2 * tid] = z0;
+                if (2 * tid + 1 < d) Y[2 * tid + 1] = z1;
+            } else if (tid == nb) {
+                double u0, u1;
+                philox_uniform2(key, gchain, (uint32_t)i, TAG_RWM_UNIFORM, 0u, u0, u1);
+                sc[0] = fm_log<true>(u0);
+            }
+        }
+        __syncthreads();
+
+        // ---- proposal theta + Y * R (:153-154): thread j owns column j ---------------------------------
+        if (tid < d) {
+            const double *col = A + tri(0, tid);
+            double s = 0.0;
+            for (int k = 0; k <= tid; ++k) s += Y[k] * col[k];
+            pr[tid] = th[tid] + s;
+        }
+        double q = 0.0;
+        for (int k = 0; k < d; ++k) q += Y[k] * Y[k];
+        const double logA = sc[0];
+        __syncthreads();
+
+        // ---- target and Metropolis-Hastings log ratio (:157-171) --------------------------------------
+        const double t_prop = target(pr);
+        double la;
+        if (!isfinite(t_prop)) {
+            la = -__builtin_inf();
+        } else {
+            la = t_prop - t_cur;
+            const double p = fm_log<true>(rootTerm * exp(-0.5 * q));
+            la = add_rn(la, p);
+            la = add_rn(la, -p);
+        }
+        const bool accept = logA < la;
+        if (accept) {
+            if (tid < d) th[tid] = pr[tid];
+            t_cur = t_prop;
+        }
+        if (FULL && tid == 0) {
+            if (a.d_accepted) a.d_accepted[(int64_t)(i - 1) * n + c] = accept ? 1 : 0;
+            if (a.d_log_acceptance) a.d_log_acceptance[(int64_t)(i - 1) * n + c] = la;
+            if (a.d_log_A) a.d_log_A[(int64_t)(i - 1) * n + c] = logA;
+        }
+        __syncthreads();
+
+        // ---- trace (:185) -------------------------------------------------------------------------------
+        const bool keep = (i % a.thin) == 0;
+        const int64_t t = i / a.thin - 1;
+        if (a.d_trace && keep && tid < d) a.d_trace[(t * d + tid) * n + c] = th[tid];
+
+        // ---- acceptance rate (:188-207), replicated ------------------------------------------------------
+        const double acc = accept ? 1.0 : 0.0;
+        if (i == 1) {
+            rate = acc;
+        } else if (wgt == 0) {
+            if (window == 0) {
+                rate = add_rn(rate, div_rn(add_rn(acc, -rate), di));
+            } else {
+                win_bits = (win_bits << 1) | (accept ? 1ull : 0ull);
+                if (win_len < window) ++win_len;
+                const uint64_t msk = (win_len >= 64) ? ~0ull : ((1ull << win_len) - 1ull);
+                rate = div_rn((double)__popcll(win_bits & msk), (double)win_len);
+            }
+        } else {
+            rate = add_rn(mul_rn(rate, 1 - wgt), mul_rn(acc, wgt));
+        }
+        if (FULL && a.d_rate_trace && tid == 0) a.d_rate_trace[(int64_t)(i - 1) * n + c] = rate;
+
+        // ---- running mean / covariance (:210-214, update_sigma :42-45) ----------------------------------
+        if (need_moments) {
+            const double im1 = di - 1.0;
+            const double sfac = im1 / di;
+            const double inv_i = 1.0 / di;
+            if (tid < d) {
+                const double mk = mn[tid];
+                const double r = th[tid] - mk;
+                v[tid] = r;
+                mn[tid] = mk + r * inv_i;
+            }
+            __syncthreads();
+            const bool sig = FULL && a.d_sigma_trace && keep;
+#pragma unroll
+            for (int qq = 0; qq < kBlockSlots; ++qq) {
+                if (rc[qq] >= 0) {
+                    const int r = rc[qq] & 255, cl = rc[qq] >> 8;
+                    const double val = (C[qq] * im1 + (sfac * v[r]) * v[cl]) * inv_i;
+                    C[qq] = val;
+                    if (sig) {
+                        a.d_sigma_trace[(t * ((int64_t)d * d) + cl * d + r) * n + c] = val;
+                        if (r != cl) a.d_sigma_trace[(t * ((int64_t)d * d) + r * d + cl) * n + c] = val;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    if (tid < d) {
+        if (a.d_final_theta) a.d_final_theta[(int64_t)tid * n + c] = th[tid];
+        if (a.d_final_mean) a.d_final_mean[(int64_t)tid * n + c] = mn[tid];
+    }
+    if (a.d_final_cov) {
+#pragma unroll
+        for (int qq = 0; qq < kBlockSlots; ++qq) {
+            if (rc[qq] >= 0) {
+                const int r = rc[qq] & 255, cl = rc[qq] >> 8;
+                a.d_final_cov[(int64_t)(cl * d + r) * n + c] = C[qq];
+                a.d_final_cov[(int64_t)(r * d + cl) * n + c] = C[qq];
+            }
+        }
+    }
+    if (tid == 0) {
+        if (a.d_acceptance_rate) a.d_acceptance_rate[c] = rate;
+        if (a.d_status) a.d_status[c] = status;
+    }
+}
+
+int launch_rwm_block(const RwmArgs &a, const RwmParams &p, hipStream_t s)
+{
+    const int d = a.d;
+    if (p.target_kind != MCMC_TARGET_GAUSSIAN_PREC)
+        return set_error(MCMC_E_BAD_ARG, "target kind %d is 2-dimensional; d=%d", p.target_kind, d);
+    if (d < 1 || d > kMaxDimRwm) return set_error(MCMC_E_UNSUPPORTED, "adaptive RWM: d=%d outside 1..%d", d, kMaxDimRwm);
+    if ((int)p.tparams.size() != d + d * d) return set_error(MCMC_E_BAD_ARG, "gaussian target needs d + d*d parameters");
+    const BlockLayout L(d);
+    std::vector<double> blob(L.total(), 0.0);
+    for (int k = 0; k < d; ++k) blob[L.init() + k] = p.init[k];
+    for (int e = 0; e < L.T; ++e) {
+        blob[L.cov() + e] = p.cov_packed[e];
+        blob[L.r0() + e] = p.R0_packed[e];
+    }
+    blob[L.root0()] = 1.0 / std::sqrt(a.twopi_pow_d * p.det0);
+    for (int e = 0; e < d + d * d; ++e) blob[L.tmean() + e] = p.tparams[e];
+    double *d_prm = nullptr;
+    MCMC_HIP_CHECK(hipMallocAsync((void **)&d_prm, blob.size() * sizeof(double), s));
+    MCMC_HIP_CHECK(hipMemcpyAsync(d_prm, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    MCMC_HIP_CHECK(hipStreamSynchronize(s)); // blob is a local: do not let the copy outlive it
+    const size_t ldsb = (size_t)L.lds_doubles() * sizeof(double);
+    const bool full = a.d_Z || a.d_sigma_trace || a.d_accepted || a.d_log_acceptance || a.d_log_A || a.d_scaling_sd ||
+                      a.d_scaling_multiplier || a.d_rate_trace;
+    hipError_t e0;
+    if (full) {
+        e0 = hipFuncSetAttribute((const void *)rwm_block_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+        if (e0 == hipSuccess)
+            hipLaunchKernelGGL((rwm_block_kernel<true>), dim3((unsigned)a.n_chains), dim3(kBlockThreads), ldsb, s, a,
+                               (const double *)d_prm);
+    } else {
+        e0 = hipFuncSetAttribute((const void *)rwm_block_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+        if (e0 == hipSuccess)
+            hipLaunchKernelGGL((rwm_block_kernel<false>), dim3((unsigned)a.n_chains), dim3(kBlockThreads), ldsb, s, a,
+                               (const double *)d_prm);
+    }
+    hipError_t e1 = hipGetLastError();
+    hipError_t e2 = hipFreeAsync(d_prm, s);
+    if (e0 != hipSuccess) return set_error(MCMC_E_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e0));
+    if (e1 != hipSuccess) return set_error(MCMC_E_HIP, "rwm_block_kernel launch failed: %s", hipGetErrorString(e1));
+    if (e2 != hipSuccess) return set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e2));
+    return MCMC_OK;
+}
+
+} // namespace mcmc

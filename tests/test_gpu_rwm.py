@@ -253,3 +253,64 @@ def test_init_normal_and_argument_validation(cuda):
         mcmc_amd.rwMCMC(tgt, [0, 0], np.array([[1.0, 0.5], [0.2, 1.0]]), 10, 1, 1.0)  # asymmetric covmat
     with pytest.raises(mcmc_amd.McmcError):
         mcmc_amd.adapt_rwm_batch(mcmc_amd.Target.goldstein_price(), 4, np.zeros(3), np.eye(3), 10)  # d != 2
+
+
+@pytest.mark.parametrize("d,n,kernel,ass,ashs", [(10, 800, "block", 50, 120), (24, 500, "auto", 40, 90), (100, 1000, "auto", 20, 160)])
+def test_block_kernel_matches_oracle(cuda, oracle, d, n, kernel, ass, ashs):
+    """One chain per 256-thread workgroup (12 < d <= 128; forced at d = 10 to compare the two kernels)."""
+    import mcmc_amd
+
+    rng = np.random.default_rng(1000 + d)
+    nc = 5 if d < 100 else 3  # adapt_shape_start must exceed d or covmat_empirical is singular (SURVEY section 7)
+    A = rng.standard_normal((d, d))
+    Sig = A @ A.T / d + np.eye(d)
+    H = np.linalg.inv(Sig)
+    H = 0.5 * (H + H.T)
+    init = rng.standard_normal((d, nc))
+    cov0 = 0.1 * np.eye(d)
+    Z = rng.standard_normal((n, d, nc))
+    U = rng.random((n, nc))
+    out = mcmc_amd.adapt_rwm_batch(mcmc_amd.Target.gaussian(np.zeros(d), H), nc, cuda.tensor(init, device="cuda"), cov0, n,
+                                   ass, 0.0, 0, ashs, Z=cuda.tensor(Z, device="cuda"), U=cuda.tensor(U, device="cuda"),
+                                   diagnostics=True, kernel=kernel, sigma_trace=(d <= 24))
+    cuda.cuda.synchronize()
+    assert np.all(out["status"].cpu().numpy() == 0)
+    tr, acc = out["theta_trace"].cpu().numpy(), out["accepted"].cpu().numpy()
+    reached = 0
+    for c in range(nc):
+        ref = oracle.adaptMCMC(oracle.gaussian_target(np.zeros(d), H), init[:, c], cov0, n, ass, 0.0, 0, ashs, Z[:, :, c],
+                               U[:, c], diagnostics=True)
+        assert _check_decisions(acc[:, c], ref["diag"]) == 0
+        assert _rel(tr[:, :, c], ref["theta_trace"]) < 1e-11, (c, _rel(tr[:, :, c], ref["theta_trace"]))
+        np.testing.assert_array_equal(out["rate_trace"].cpu().numpy()[:, c], ref["diag"]["acceptance_rate"])
+        np.testing.assert_allclose(out["final_cov"].cpu().numpy()[:, c].reshape(d, d, order="F"),
+                                   ref["sigma_empirical"][:, :, -1], rtol=1e-9, atol=1e-12)
+        if d <= 24:
+            sg = out["sigma_empirical"].cpu().numpy()[:, :, c].reshape(n, d, d).transpose(2, 1, 0)
+            np.testing.assert_allclose(sg[:, :, -1], ref["sigma_empirical"][:, :, -1], rtol=1e-9, atol=1e-12)
+        reached += ref["diag"]["scaling_sd"][-1] == pytest.approx(2.38 / np.sqrt(d))
+    assert reached >= 1
+
+
+def test_block_kernel_philox_sharding_and_failure(cuda, oracle):
+    import mcmc_amd
+
+    d = 20
+    rng = np.random.default_rng(9)
+    A = rng.standard_normal((d, d))
+    H = np.linalg.inv(A @ A.T / d + np.eye(d))
+    H = 0.5 * (H + H.T)
+    tgt = mcmc_amd.Target.gaussian(np.zeros(d), H)
+    kw = dict(adapt_size_start=20, adapt_shape_start=80, seed=77)
+    whole = mcmc_amd.adapt_rwm_batch(tgt, 12, np.zeros(d), 0.05 * np.eye(d), 300, **kw)
+    part = mcmc_amd.adapt_rwm_batch(tgt, 5, np.zeros(d), 0.05 * np.eye(d), 300, chain_offset=7, **kw)
+    assert cuda.equal(whole["theta_trace"][:, :, 7:], part["theta_trace"])
+    # replay of the Philox streams through the oracle
+    Z, U = mcmc_amd.rwm_streams(77, 12, 300, d)
+    ref = oracle.adaptMCMC(oracle.gaussian_target(np.zeros(d), H), np.zeros(d), 0.05 * np.eye(d), 300, 20, 0.0, 0, 80,
+                           Z.cpu().numpy()[:, :, 3], U.cpu().numpy()[:, 3], store_sigma=False)
+    assert _rel(whole["theta_trace"].cpu().numpy()[:, :, 3], ref["theta_trace"]) < 1e-11
+    # rank-deficient covmat_empirical -> chol failure reported with its iteration (adaptMCMC_source.cpp:153)
+    out = mcmc_amd.adapt_rwm_batch(tgt, 3, np.zeros(d), 0.05 * np.eye(d), 100, 0, 0.0, 0, 1, seed=5, kernel="block")
+    st = out["status"].cpu().numpy()
+    assert np.all((st & 15) == mcmc_amd.MCMC_CHAIN_CHOL_FAILED) and np.all((st >> 4) >= 2)
