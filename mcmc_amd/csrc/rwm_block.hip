@@ -8,18 +8,21 @@
 //   * R, the upper Cholesky factor of covmat_proposal, packed by columns, in LDS (T = d(d+1)/2
 //     doubles) together with theta, theta_mean, the normals Y, the proposal and two scratch vectors:
 //     45 KB at d = 100, so three chains share the 160 KB of a CU (12 waves, 3 per SIMD);
-//   * covmat_empirical in REGISTERS, packed element e of thread t at slot q with e = 256 q + t
-//     (<= 33 slots at d = 128).  It is only ever touched element-wise (the rank-1 update_sigma and
-//     the copy s^2 * C -> LDS that feeds the factorization), so no thread needs another's slice;
+//   * covmat_empirical in REGISTERS, 2-D cyclic over the 16 x 16 threads: thread (ti, tk) owns the
+//     elements (16a + ti, 16b + tk), a <= b, of the upper triangle (NT(NT+1)/2 doubles, NT = ceil(d/16)).
+//     It is only ever touched element-wise (the rank-1 update_sigma), and the factorization works
+//     on a register copy s^2 * C in the same layout, so no thread needs another's slice;
 //   * shared parameters (covmat, chol(covmat), target mean and precision) stay in HBM/L2 and are
 //     read coalesced (the precision matrix column-major, thread i reading row i).
 // Scalars of the chain (acceptance rate, scaling_sd, cached target value, ...) are replicated in
 // every thread, so decisions are taken without a broadcast.
 //
-// The factorization is the right-looking (outer-product) Cholesky in place in LDS, threads arranged
-// 16 x 16 over the trailing matrix.  It is the same arithmetic as the reference's dpotrf per element
-// but in a different summation order than the one-lane kernel; FP64 MFMA blocking is the planned
-// replacement.
+// The factorization is the right-looking (outer-product) Cholesky with the trailing matrix held in
+// registers: at step j the owners of row j publish it (unscaled, pivot included) in a double-buffered
+// LDS row, ONE barrier, then every thread scales the 2 NT entries it needs by 1/sqrt(pivot) and
+// updates its tile with NT(NT+1)/2 FMAs; the owners also store the finished row of R to LDS.  Same
+// arithmetic per element as the reference's dpotrf, different summation order than the one-lane
+// kernel; FP64 MFMA blocking is the planned replacement.
 #include "common.h"
 #include "philox.h"
 #include "targets.h"
@@ -27,7 +30,7 @@
 namespace mcmc {
 
 constexpr int kBlockThreads = 256;
-constexpr int kBlockSlots = (kMaxDimRwm * (kMaxDimRwm + 1) / 2 + kBlockThreads - 1) / kBlockThreads; // 33
+__host__ __device__ constexpr int blk(int a, int b) { return b * (b + 1) / 2 + a; } // tile block (a,b), a <= b
 
 // parameter block (doubles): init[d] cov[T] R0[T] root0 tmean[d] H[d*d]
 struct BlockLayout {
@@ -40,11 +43,11 @@ struct BlockLayout {
     __host__ __device__ int tmean() const { return d + 2 * T + 1; }
     __host__ __device__ int H() const { return 2 * d + 2 * T + 1; }
     __host__ __device__ int total() const { return 2 * d + 2 * T + 1 + d * d; }
-    __host__ __device__ int lds_doubles() const { return T + 6 * d + 8; }
+    __host__ __device__ int lds_doubles() const { return T + 6 * d + 8 + 2 * 16 * ((d + 15) / 16); }
 };
 
-template <bool FULL>
-__global__ __launch_bounds__(kBlockThreads) void rwm_block_kernel(const RwmArgs a, const double *__restrict__ prm)
+template <int NT, bool FULL>
+__global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmArgs a, const double *__restrict__ prm)
 {
     extern __shared__ double lds[];
     const int d = a.d;
@@ -59,6 +62,8 @@ __global__ __launch_bounds__(kBlockThreads) void rwm_block_kernel(const RwmArgs 
     double *const v = pr + d;     // scratch: x - mean of the target, residual
     double *const w = v + d;      // scratch: v_i * (H v)_i
     double *const sc = w + d;     // sc[0] = log(A)
+    double *const raw = sc + 8;   // two unscaled pivot rows (double buffer), 16 NT doubles each
+    constexpr int NB = NT * (NT + 1) / 2;
     const int64_t c = blockIdx.x;
     const int64_t n = a.n_chains;
     const uint64_t gchain = (uint64_t)(a.chain_offset + c);
@@ -72,18 +77,10 @@ __global__ __launch_bounds__(kBlockThreads) void rwm_block_kernel(const RwmArgs 
     const double *__restrict__ H = prm + L.H();
     const int ti = tid & 15, tk = tid >> 4;
 
-    // covmat_empirical slice in registers + the (row, col) of every slot
-    double C[kBlockSlots];
-    int rc[kBlockSlots];
+    // covmat_empirical tile (registers) and the working copy the factorization consumes
+    double Ct[NB], At[NB];
 #pragma unroll
-    for (int q = 0; q < kBlockSlots; ++q) {
-        C[q] = 0.0;
-        const int e = q * kBlockThreads + tid;
-        int col = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
-        while ((col + 1) * (col + 2) / 2 <= e) ++col;
-        while (col * (col + 1) / 2 > e) --col;
-        rc[q] = (e < T) ? ((e - col * (col + 1) / 2) | (col << 8)) : -1;
-    }
+    for (int q = 0; q < NB; ++q) Ct[q] = 0.0;
     for (int e = tid; e < T; e += kBlockThreads) A[e] = prm[L.r0() + e];
     if (tid < d) {
         const double x0 = a.d_init ? a.d_init[(int64_t)tid * n + c] : prm[L.init() + tid];
@@ -98,7 +95,15 @@ __global__ __launch_bounds__(kBlockThreads) void rwm_block_kernel(const RwmArgs 
         __syncthreads();
         if (tid < d) {
             double s = 0.0;
-            for (int j = 0; j < d; ++j) s += H[(int64_t)j * d + tid] * v[j];
+            int j = 0;
+            for (; j + 8 <= d; j += 8) { // eight coalesced loads in flight, then the oracle's left-to-right sum
+                double h[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) h[u] = H[(int64_t)(j + u) * d + tid];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += h[u] * v[j + u];
+            }
+            for (; j < d; ++j) s += H[(int64_t)j * d + tid] * v[j];
             w[tid] = mul_rn(v[tid], s);
         }
         __syncthreads();
@@ -141,37 +146,60 @@ __global__ __launch_bounds__(kBlockThreads) void rwm_block_kernel(const RwmArgs 
 
         // ---- R = chol(covmat_proposal) when it was assigned (:153) --------------------------------
         if (dirty && !dead) { // uniform over the workgroup
-            if (use_emp) {
 #pragma unroll
-                for (int q = 0; q < kBlockSlots; ++q)
-                    if (rc[q] >= 0) A[q * kBlockThreads + tid] = s2 * C[q];
-            } else {
-                for (int e = tid; e < T; e += kBlockThreads) A[e] = s2 * prm[L.cov() + e];
+            for (int bb = 0; bb < NT; ++bb) {
+#pragma unroll
+                for (int aa = 0; aa <= bb; ++aa) {
+                    const int ii = 16 * aa + ti, kk = 16 * bb + tk;
+                    double src = Ct[blk(aa, bb)];
+                    if (!use_emp) src = (ii <= kk && kk < d) ? prm[L.cov() + tri(ii, kk)] : 0.0;
+                    At[blk(aa, bb)] = s2 * src;
+                }
             }
-            __syncthreads();
             bool ok = true;
             double prod = 1.0;
-            for (int j = 0; j < d; ++j) {
-                const double ajj = A[tri(j, j)];
-                ok = ok && (ajj > 0.0);
-                double rjj, rinv;
-                fm_sqrt_rsq(ajj, rjj, rinv);
-                prod *= rjj;
-                for (int k = j + 1 + tid; k < d; k += kBlockThreads) A[tri(j, k)] *= rinv; // row j of R
-                __syncthreads();
-                if (tid == 0) A[tri(j, j)] = rjj;
-                // trailing update A(i,k) -= R(j,i) R(j,k), j < i <= k, threads 16 x 16 over (i, k)
-                const int m = d - 1 - j;
-                for (int ib = 0; ib * 16 < m; ++ib) {
-                    const int ii = j + 1 + ib * 16 + ti;
-                    const double rji = (ii < d) ? A[tri(j, ii)] : 0.0;
-                    for (int kb = ib; kb * 16 < m; ++kb) {
-                        const int kk = j + 1 + kb * 16 + tk;
-                        if (ii <= kk && kk < d) A[tri(ii, kk)] -= rji * A[tri(j, kk)];
+#pragma unroll
+            for (int a0 = 0; a0 < NT; ++a0) {
+                for (int jt = 0; jt < 16; ++jt) {
+                    const int j = 16 * a0 + jt;
+                    if (j >= d) break;
+                    double *const row = raw + (j & 1) * (16 * NT);
+                    if (ti == jt) { // owners of row j publish it unscaled (pivot included)
+#pragma unroll
+                        for (int bb = a0; bb < NT; ++bb) {
+                            const int kk = 16 * bb + tk;
+                            if (kk >= j && kk < d) row[kk] = At[blk(a0, bb)];
+                        }
+                    }
+                    __syncthreads();
+                    const double ajj = row[j];
+                    ok = ok && (ajj > 0.0);
+                    double rjj, rinv;
+                    fm_sqrt_rsq(ajj, rjj, rinv);
+                    prod *= rjj;
+                    double ri[NT], rk[NT];
+#pragma unroll
+                    for (int x = a0; x < NT; ++x) {
+                        const int ii = 16 * x + ti, kk = 16 * x + tk;
+                        ri[x] = (ii > j && ii < d) ? row[ii] * rinv : 0.0;
+                        rk[x] = (kk > j && kk < d) ? row[kk] * rinv : 0.0;
+                    }
+                    if (ti == jt) { // finished row j of R -> LDS (packed by columns)
+#pragma unroll
+                        for (int bb = a0; bb < NT; ++bb) {
+                            const int kk = 16 * bb + tk;
+                            if (kk > j && kk < d) A[tri(j, kk)] = rk[bb];
+                            if (kk == j) A[tri(j, j)] = rjj;
+                        }
+                    }
+#pragma unroll
+                    for (int bb = a0; bb < NT; ++bb) {
+#pragma unroll
+                        for (int aa = a0; aa <= bb; ++aa) At[blk(aa, bb)] -= ri[aa] * rk[bb];
                     }
                 }
-                __syncthreads();
             }
+            __syncthreads();
             rootTerm = 1.0 / sqrt(a.twopi_pow_d * (prod * prod));
             if (!ok) { // arma::chol throws here; the chain stops and reports where
                 dead = true;
@@ -271,15 +299,24 @@ __global__ __launch_bounds__(kBlockThreads) void rwm_block_kernel(const RwmArgs 
             }
             __syncthreads();
             const bool sig = FULL && a.d_sigma_trace && keep;
+            double rv[NT], cv[NT];
 #pragma unroll
-            for (int qq = 0; qq < kBlockSlots; ++qq) {
-                if (rc[qq] >= 0) {
-                    const int r = rc[qq] & 255, cl = rc[qq] >> 8;
-                    const double val = (C[qq] * im1 + (sfac * v[r]) * v[cl]) * inv_i;
-                    C[qq] = val;
+            for (int x = 0; x < NT; ++x) {
+                rv[x] = (16 * x + ti < d) ? sfac * v[16 * x + ti] : 0.0;
+                cv[x] = (16 * x + tk < d) ? v[16 * x + tk] : 0.0;
+            }
+#pragma unroll
+            for (int bb = 0; bb < NT; ++bb) {
+#pragma unroll
+                for (int aa = 0; aa <= bb; ++aa) {
+                    const double val = (Ct[blk(aa, bb)] * im1 + rv[aa] * cv[bb]) * inv_i;
+                    Ct[blk(aa, bb)] = val;
                     if (sig) {
-                        a.d_sigma_trace[(t * ((int64_t)d * d) + cl * d + r) * n + c] = val;
-                        if (r != cl) a.d_sigma_trace[(t * ((int64_t)d * d) + r * d + cl) * n + c] = val;
+                        const int r = 16 * aa + ti, cl = 16 * bb + tk;
+                        if (r <= cl && cl < d) {
+                            a.d_sigma_trace[(t * ((int64_t)d * d) + cl * d + r) * n + c] = val;
+                            if (r != cl) a.d_sigma_trace[(t * ((int64_t)d * d) + r * d + cl) * n + c] = val;
+                        }
                     }
                 }
             }
@@ -293,11 +330,14 @@ __global__ __launch_bounds__(kBlockThreads) void rwm_block_kernel(const RwmArgs 
     }
     if (a.d_final_cov) {
 #pragma unroll
-        for (int qq = 0; qq < kBlockSlots; ++qq) {
-            if (rc[qq] >= 0) {
-                const int r = rc[qq] & 255, cl = rc[qq] >> 8;
-                a.d_final_cov[(int64_t)(cl * d + r) * n + c] = C[qq];
-                a.d_final_cov[(int64_t)(r * d + cl) * n + c] = C[qq];
+        for (int bb = 0; bb < NT; ++bb) {
+#pragma unroll
+            for (int aa = 0; aa <= bb; ++aa) {
+                const int r = 16 * aa + ti, cl = 16 * bb + tk;
+                if (r <= cl && cl < d) {
+                    a.d_final_cov[(int64_t)(cl * d + r) * n + c] = Ct[blk(aa, bb)];
+                    a.d_final_cov[(int64_t)(r * d + cl) * n + c] = Ct[blk(aa, bb)];
+                }
             }
         }
     }
@@ -330,17 +370,18 @@ int launch_rwm_block(const RwmArgs &a, const RwmParams &p, hipStream_t s)
     const size_t ldsb = (size_t)L.lds_doubles() * sizeof(double);
     const bool full = a.d_Z || a.d_sigma_trace || a.d_accepted || a.d_log_acceptance || a.d_log_A || a.d_scaling_sd ||
                       a.d_scaling_multiplier || a.d_rate_trace;
-    hipError_t e0;
-    if (full) {
-        e0 = hipFuncSetAttribute((const void *)rwm_block_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    hipError_t e0 = hipSuccess;
+    auto go = [&](auto kern) {
+        e0 = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
         if (e0 == hipSuccess)
-            hipLaunchKernelGGL((rwm_block_kernel<true>), dim3((unsigned)a.n_chains), dim3(kBlockThreads), ldsb, s, a,
-                               (const double *)d_prm);
-    } else {
-        e0 = hipFuncSetAttribute((const void *)rwm_block_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-        if (e0 == hipSuccess)
-            hipLaunchKernelGGL((rwm_block_kernel<false>), dim3((unsigned)a.n_chains), dim3(kBlockThreads), ldsb, s, a,
-                               (const double *)d_prm);
+            hipLaunchKernelGGL(kern, dim3((unsigned)a.n_chains), dim3(kBlockThreads), ldsb, s, a, (const double *)d_prm);
+    };
+    switch ((d + 15) / 16) {
+#define MCMC_CASE(NT) \
+    case NT: if (full) go(rwm_block_kernel<NT, true>); else go(rwm_block_kernel<NT, false>); break;
+        MCMC_CASE(1) MCMC_CASE(2) MCMC_CASE(3) MCMC_CASE(4) MCMC_CASE(5) MCMC_CASE(6) MCMC_CASE(7) MCMC_CASE(8)
+#undef MCMC_CASE
+    default: e0 = hipErrorInvalidValue;
     }
     hipError_t e1 = hipGetLastError();
     hipError_t e2 = hipFreeAsync(d_prm, s);

@@ -48,7 +48,7 @@ def rwm(d, chains, iters, trace=True):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", nargs="*", default=["gibbs", "rwm"])
+    ap.add_argument("what", nargs="*", default=["gibbs", "rwm"])  # also: block
     args = ap.parse_args()
     if "gibbs" in args.what:
         gibbs(10, 1 << 20, 200)
@@ -63,3 +63,27 @@ if __name__ == "__main__":
         rwm(10, 1 << 18, 1000)
         rwm(4, 1 << 18, 2000)
         rwm(2, 1 << 18, 2000)
+
+
+def rwm_block(d, chains, iters, ass=1, ashs=0, thin=10):
+    rng = np.random.default_rng(4)
+    A = rng.standard_normal((d, d))
+    Sig = A @ A.T / d + np.eye(d)
+    H = np.linalg.inv(Sig); H = 0.5 * (H + H.T)
+    tgt = mcmc_amd.Target.gaussian(np.zeros(d), H)
+    f = lambda: mcmc_amd.adapt_rwm_batch(tgt, chains, np.zeros(d), 0.01 * np.eye(d), iters, ass, 0.0, 0, ashs, seed=1, thin=thin,
+                                         final=False)
+    ms = timeit(f, reps=2)
+    rate = chains * iters / (ms * 1e-3)
+    fl = d ** 3 / 3 + 4.5 * d * d + 8.5 * d
+    print(f"rwm-block d={d} chains={chains} iters={iters} ass={ass}: {ms:.2f} ms  {rate:.3e} chain-iter/s  {rate*fl/1e12:.2f} TF alg "
+          f"({rate*fl/78.6e12*100:.1f}% of FP64 peak)")
+
+
+if __name__ == "__main__" and "block" in sys.argv:
+    rwm_block(100, 4096, 100)
+    rwm_block(100, 768, 200)
+    rwm_block(100, 4096, 100, ass=0)
+    rwm_block(128, 2048, 100)
+    rwm_block(32, 8192, 200)
+    rwm_block(16, 16384, 200)
