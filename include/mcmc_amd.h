@@ -57,10 +57,13 @@ extern "C" {
 #define MCMC_RNG_INJECTED 1
 
 /* ----- kernel choice for the Metropolis path ----------------------------------------- */
-#define MCMC_KERNEL_AUTO 0   /* one chain per lane for d <= mcmc_amd_max_lane_dim(), else per workgroup */
+#define MCMC_KERNEL_AUTO 0   /* one chain per lane for d <= mcmc_amd_max_lane_dim() (the paired-wave variant when it
+                                serves the request), else per workgroup                             */
 #define MCMC_KERNEL_LANE 1   /* one chain per lane (register-resident state), d <= 12               */
 #define MCMC_KERNEL_BLOCK 2  /* one chain per 256-thread workgroup (LDS-resident factor), d <= 128,
                                 Gaussian target only                                               */
+#define MCMC_KERNEL_PAIR 3   /* one chain per lane, a sampler and a generator wavefront per 64 chains;
+                                Philox streams, no per-iteration diagnostics, d <= 10              */
 
 /* ----- target log-densities --------------------------------------------------------- */
 /*
@@ -107,7 +110,7 @@ typedef struct mcmc_rwm_config {
     double max_scaling_sd;         /* reference default 50.0                                 */
     uint64_t seed;                 /* Philox key                                             */
     int32_t rng_mode;              /* MCMC_RNG_PHILOX | MCMC_RNG_INJECTED                     */
-    int32_t kernel;                /* MCMC_KERNEL_AUTO (0) | MCMC_KERNEL_LANE | MCMC_KERNEL_BLOCK: which device kernel runs */
+    int32_t kernel;                /* MCMC_KERNEL_AUTO (0) | _LANE | _BLOCK | _PAIR: which device kernel runs */
 } mcmc_rwm_config;
 
 typedef struct mcmc_rwm_io {
@@ -132,6 +135,8 @@ typedef struct mcmc_rwm_io {
     double *d_scaling_sd;          /* scaling_sd after the adaptation block :117-139          */
     double *d_scaling_multiplier;  /* scaling_multiplier after the adaptation block (:123)    */
     double *d_rate_trace;          /* acceptance_rate after :188-207                          */
+    /* summary, may be NULL */
+    int32_t *d_shape_iterations;   /* [n_chains] iterations whose proposal used scaling_sd^2 covmat_empirical (:131-139) */
 } mcmc_rwm_io;
 
 int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_config *cfg,

@@ -27,6 +27,7 @@ MCMC_RNG_INJECTED = 1
 MCMC_KERNEL_AUTO = 0
 MCMC_KERNEL_LANE = 1
 MCMC_KERNEL_BLOCK = 2
+MCMC_KERNEL_PAIR = 3
 
 MCMC_TARGET_GAUSSIAN_PREC = 0
 MCMC_TARGET_GOLDSTEIN_PRICE = 1
@@ -59,7 +60,7 @@ class RwmIO(C.Structure):
         ("d_trace", vp), ("d_sigma_trace", vp), ("d_final_theta", vp), ("d_final_mean", vp),
         ("d_final_cov", vp), ("d_acceptance_rate", vp), ("d_status", vp),
         ("d_accepted", vp), ("d_log_acceptance", vp), ("d_log_A", vp), ("d_scaling_sd", vp),
-        ("d_scaling_multiplier", vp), ("d_rate_trace", vp),
+        ("d_scaling_multiplier", vp), ("d_rate_trace", vp), ("d_shape_iterations", vp),
     ]
 
 

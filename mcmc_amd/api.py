@@ -256,11 +256,13 @@ def adapt_rwm_batch(target, n_chains, init_theta, covmat, n_iterations, adapt_si
     init_theta: length-d vector shared by all chains, or a [d, n_chains] CUDA tensor.
     Z [n_iterations, d, n_chains], U [n_iterations, n_chains]: injected streams (CUDA, f64).
     Returns a dict of CUDA tensors: theta_trace [n_kept, d, n_chains], acceptance_rate
-    [n_chains], status [n_chains], final_theta / final_mean [d, n_chains], final_cov
+    [n_chains], status [n_chains], shape_iterations [n_chains] (iterations proposed from the
+    shape-adapted covariance), final_theta / final_mean [d, n_chains], final_cov
     [d*d, n_chains], and with diagnostics=True accepted / log_acceptance / log_A /
     scaling_sd / scaling_multiplier / rate_trace, each [n_iterations, n_chains].
-    `out` may carry preallocated tensors under the same keys.  kernel = "auto" | "lane" | "block"
-    picks the device kernel (auto: per lane for d <= 12, per 256-thread workgroup above).
+    `out` may carry preallocated tensors under the same keys.  kernel = "auto" | "lane" | "pair" |
+    "block" picks the device kernel (auto: per lane for d <= 12 -- the paired-wave variant for Philox runs
+    without diagnostics at d <= 10 -- and per 256-thread workgroup above).
     """
     torch = _torch()
     t = _need_target(target)
@@ -296,7 +298,8 @@ def adapt_rwm_batch(target, n_chains, init_theta, covmat, n_iterations, adapt_si
                       adapt_size_cooling=float(adapt_size_cooling), max_scaling_sd=float(max_scaling_sd),
                       seed=int(seed) & 0xFFFFFFFFFFFFFFFF,
                       rng_mode=L.MCMC_RNG_INJECTED if Z is not None else L.MCMC_RNG_PHILOX,
-                      kernel={"auto": L.MCMC_KERNEL_AUTO, "lane": L.MCMC_KERNEL_LANE, "block": L.MCMC_KERNEL_BLOCK}[kernel])
+                      kernel={"auto": L.MCMC_KERNEL_AUTO, "lane": L.MCMC_KERNEL_LANE, "block": L.MCMC_KERNEL_BLOCK,
+                              "pair": L.MCMC_KERNEL_PAIR}[kernel])
     if (Z is None) != (U is None):
         raise ValueError("give both Z and U, or neither")
     if Z is not None:
@@ -315,6 +318,7 @@ def adapt_rwm_batch(target, n_chains, init_theta, covmat, n_iterations, adapt_si
     io.d_final_cov = _dev_ptr(buf("final_cov", (d * d, n_chains), want=final))
     io.d_acceptance_rate = _dev_ptr(buf("acceptance_rate", (n_chains,)))
     io.d_status = _dev_ptr(buf("status", (n_chains,), torch.int32))
+    io.d_shape_iterations = _dev_ptr(buf("shape_iterations", (n_chains,), torch.int32), torch.int32)
     if diagnostics:
         io.d_accepted = _dev_ptr(buf("accepted", (n, n_chains), torch.uint8))
         io.d_log_acceptance = _dev_ptr(buf("log_acceptance", (n, n_chains)))

@@ -139,7 +139,7 @@ extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_co
         return set_error(MCMC_E_BAD_ARG, "unknown rng_mode %d", cfg->rng_mode);
     }
     if (d > kMaxDimRwm) return set_error(MCMC_E_UNSUPPORTED, "adaptive RWM: d=%d above the limit %d", d, kMaxDimRwm);
-    if (cfg->kernel < MCMC_KERNEL_AUTO || cfg->kernel > MCMC_KERNEL_BLOCK)
+    if (cfg->kernel < MCMC_KERNEL_AUTO || cfg->kernel > MCMC_KERNEL_PAIR)
         return set_error(MCMC_E_BAD_ARG, "unknown kernel choice %d", cfg->kernel);
     if (cfg->kernel == MCMC_KERNEL_LANE && d > kMaxLaneDimRwm)
         return set_error(MCMC_E_UNSUPPORTED, "one-chain-per-lane kernel: d=%d above its limit %d", d, kMaxLaneDimRwm);
@@ -177,6 +177,7 @@ extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_co
     a.d_final_cov = io->d_final_cov;
     a.d_acceptance_rate = io->d_acceptance_rate;
     a.d_status = io->d_status;
+    a.d_shape_iterations = io->d_shape_iterations;
     a.d_accepted = io->d_accepted;
     a.d_log_acceptance = io->d_log_acceptance;
     a.d_log_A = io->d_log_A;
@@ -195,7 +196,12 @@ extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_co
         MCMC_HIP_CHECK(hipStreamSynchronize(s)); // `cool` is a local: do not let the copy outlive it
         a.d_cool_pow = d_cool;
     }
-    rc = use_block ? launch_rwm_block(a, p, s) : launch_rwm_lane(a, p, s);
+    if (use_block)
+        rc = launch_rwm_block(a, p, s);
+    else if (cfg->kernel == MCMC_KERNEL_PAIR || (cfg->kernel == MCMC_KERNEL_AUTO && rwm_pair_serves(a)))
+        rc = launch_rwm_pair(a, p, s);
+    else
+        rc = launch_rwm_lane(a, p, s);
     if (d_cool) {
         hipError_t e = hipFreeAsync(d_cool, s);
         if (rc == MCMC_OK && e != hipSuccess) rc = set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e));

@@ -14,6 +14,8 @@ namespace mcmc {
 
 // largest d handled by the register-resident one-chain-per-lane kernels
 constexpr int kMaxLaneDimRwm = 12;
+// largest d of the paired-wave variant (sampler + generator wavefront per 64 chains, <= 256 registers each)
+constexpr int kMaxPairDimRwm = 10;
 // largest d of the LDS-resident kernels (one 64-lane workgroup must fit 160 KiB of LDS)
 constexpr int kMaxDimGibbs = 256;
 constexpr int kMaxDimRwm = 128;
@@ -84,6 +86,7 @@ struct RwmArgs {
     double *d_final_cov;
     double *d_acceptance_rate;
     int32_t *d_status;
+    int32_t *d_shape_iterations;
     uint8_t *d_accepted;
     double *d_log_acceptance;
     double *d_log_A;
@@ -104,6 +107,8 @@ struct RwmParams {
 
 int launch_rwm_lane(const RwmArgs &a, const RwmParams &p, hipStream_t s);
 int launch_rwm_block(const RwmArgs &a, const RwmParams &p, hipStream_t s);
+bool rwm_pair_serves(const RwmArgs &a);
+int launch_rwm_pair(const RwmArgs &a, const RwmParams &p, hipStream_t s);
 int launch_rwm_streams(uint64_t seed, int64_t chain_offset, int64_t n_chains, int32_t n_iterations,
                        int32_t d, double *d_Z, double *d_U, hipStream_t s);
 int launch_init_normal(uint64_t seed, int64_t chain_offset, int64_t n_chains, int32_t d,

@@ -33,6 +33,16 @@ __device__ __forceinline__ double div_rn(double a, double b)
     return a / b;
 }
 
+// A double constant delivered through a scalar register pair, re-materialized at every use (two s_mov_b32).
+// Without it the compiler hoists the 64-bit polynomial coefficients of log / exp out of the sampling loops
+// into VECTOR registers (an FP64 literal cannot be an instruction operand on gfx950) and then spills them:
+// measured in rwm_pair.hip, 40 spilled VGPRs were coefficients.
+__device__ __forceinline__ double sconst(double x)
+{
+    asm volatile("" : "+s"(x));
+    return x;
+}
+
 // a / b for finite, normal, well-scaled operands; error <= ~1.5 ulp.
 __device__ __forceinline__ double fm_rcp(double b)
 {
@@ -75,25 +85,54 @@ __device__ __forceinline__ double fm_log(double x)
 {
     int e;
     double m = frexp(x, &e); // m in [0.5, 1); v_frexp_* normalise subnormals themselves
-    const bool lo = m < 0.70710678118654752440;
+    const bool lo = m < sconst(0.70710678118654752440);
     m = lo ? m + m : m;
     e = lo ? e - 1 : e;
     const double f = m - 1.0;
     const double s = f * fm_rcp(2.0 + f);
     const double z = s * s;
     const double w = z * z;
-    const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
-    const double t2 = z * (6.666666666666735130e-01 +
-                           w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+    const double t1 = w * (sconst(3.999999999940941908e-01) +
+                           w * (sconst(2.222219843214978396e-01) + w * sconst(1.531383769920937332e-01)));
+    const double t2 = z * (sconst(6.666666666666735130e-01) +
+                           w * (sconst(2.857142874366239149e-01) +
+                                w * (sconst(1.818357216161805012e-01) + w * sconst(1.479819860511658591e-01))));
     const double R = t2 + t1;
     const double hfsq = 0.5 * f * f;
     const double dk = (double)e;
-    double res = dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+    double res = dk * sconst(6.93147180369123816490e-01) - ((hfsq - (s * (hfsq + R) + dk * sconst(1.90821492927058770002e-10))) - f);
     if (FULL) {
         if (x == 0.0) res = -__builtin_inf();
         if (x < 0.0 || x != x) res = __builtin_nan("");
         if (x == __builtin_inf()) res = x;
     }
+    return res;
+}
+
+// exp(x): x = k ln2 + r, |r| <= ln2/2, degree-13 Taylor polynomial in r (truncation 4e-18), ldexp.
+// <= 1 ulp on [-745, 709]; 0 / +Inf beyond, NaN propagates.  Coefficients come through scalar registers.
+__device__ __forceinline__ double fm_exp(double x)
+{
+    const double xc = fmin(fmax(x, -1100.0), 1100.0); // keeps k inside int range; the result is 0 / Inf there anyway
+    const double kd = rint(xc * sconst(1.4426950408889634074));
+    double r = fma(kd, -sconst(6.93147180369123816490e-01), xc);
+    r = fma(kd, -sconst(1.90821492927058770002e-10), r);
+    double p = sconst(1.6059043836821613e-10);          // 1/13!
+    p = fma(p, r, sconst(2.08767569878681e-09));          // 1/12!
+    p = fma(p, r, sconst(2.505210838544172e-08));         // 1/11!
+    p = fma(p, r, sconst(2.755731922398589e-07));         // 1/10!
+    p = fma(p, r, sconst(2.7557319223985893e-06));        // 1/9!
+    p = fma(p, r, sconst(2.48015873015873e-05));          // 1/8!
+    p = fma(p, r, sconst(0.0001984126984126984));         // 1/7!
+    p = fma(p, r, sconst(0.001388888888888889));          // 1/6!
+    p = fma(p, r, sconst(0.008333333333333333));          // 1/5!
+    p = fma(p, r, sconst(0.041666666666666664));          // 1/4!
+    p = fma(p, r, sconst(0.16666666666666666));           // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    double res = ldexp(p, (int)kd);
+    if (x != x) res = x;
     return res;
 }
 

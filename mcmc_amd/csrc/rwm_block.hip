@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
     double rate = 0.0, scaling_sd = 1.0, scaling_multiplier = 1.0;
     uint64_t win_bits = 0;
     int win_len = 0;
-    int32_t status = MCMC_CHAIN_OK;
+    int32_t status = MCMC_CHAIN_OK, n_shape = 0;
     bool dead = false;
 
     for (int i = 1; i <= a.n_iterations; ++i) {
@@ -138,6 +138,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
             s2 = mul_rn(scaling_sd, scaling_sd);
             dirty = true;
             use_emp = true;
+            ++n_shape;
         }
         if (FULL && tid == 0) {
             if (a.d_scaling_sd) a.d_scaling_sd[(int64_t)(i - 1) * n + c] = scaling_sd;
@@ -344,6 +345,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
     if (tid == 0) {
         if (a.d_acceptance_rate) a.d_acceptance_rate[c] = rate;
         if (a.d_status) a.d_status[c] = status;
+        if (a.d_shape_iterations) a.d_shape_iterations[c] = n_shape;
     }
 }
 

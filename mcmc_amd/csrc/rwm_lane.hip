@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const dou
     double rate = 0.0, scaling_sd = 1.0, scaling_multiplier = 1.0;
     uint64_t win_bits = 0;
     int win_len = 0;
-    int32_t status = MCMC_CHAIN_OK;
+    int32_t status = MCMC_CHAIN_OK, n_shape = 0;
     bool dead = false;
 
     for (int i = 1; i <= a.n_iterations; ++i) {
@@ -117,6 +117,7 @@ __global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const dou
             s2 = mul_rn(scaling_sd, scaling_sd);
             dirty = true;
             use_emp = true;
+            ++n_shape;
         }
         if (FULL && a.d_scaling_sd && live) a.d_scaling_sd[(int64_t)(i - 1) * n + c] = scaling_sd;
         if (FULL && a.d_scaling_multiplier && live) a.d_scaling_multiplier[(int64_t)(i - 1) * n + c] = scaling_multiplier;
@@ -281,6 +282,7 @@ __global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const dou
         }
         if (a.d_acceptance_rate) a.d_acceptance_rate[c] = rate;
         if (a.d_status) a.d_status[c] = status;
+        if (a.d_shape_iterations) a.d_shape_iterations[c] = n_shape;
     }
 }
 

@@ -1,0 +1,490 @@
+// Adaptive random-walk Metropolis, one chain per lane, a SAMPLER and a GENERATOR wavefront per 64
+// chains (gfx950), d <= 10.  Same loop as rwm_lane.hip (adaptMCMC_source.cpp:108-216; rwMCMC :252-313).
+//
+// Why two wavefronts.  The one-wave kernel needs > 256 registers, so one wave per SIMD is resident, and
+// ONE wave issues an FP64 instruction only every ~11 cycles (tools/ubench_isa.hip, measured: 4.8 cycles
+// is the SIMD's rate with several waves).  BASELINE config 2 has 65 536 chains = 1 024 waves for the
+// 1 024 SIMDs of an MI355X, so more chains per SIMD are not available; the parallelism that is, is
+// inside an iteration: everything that depends only on (seed, chain, iteration) -- the d Box-Muller
+// normals from Philox, exp(-|Y|^2/2) of the Hastings term (:62), log(A) of the acceptance uniform
+// (:174-175), the (i-1)/i and 1/i factors of update_sigma (:43) -- is 40 % of the instructions and has
+// no dependence on the chain state.
+//
+// Layout.  A workgroup is 8 wavefronts = 256 chains: waves 0..3 sample chain groups 0..3, wave 4+g
+// generates for group g one iteration ahead and hands over through a 6 KB LDS buffer between two
+// adjacent barriers.  On MI355X wave w and wave w+4 of a workgroup are placed on the same SIMD
+// (tools/probe_hwid.hip, measured on all workgroups), so every SIMD holds one sampler and its own
+// generator, whose instructions fill the sampler's issue gaps.  One workgroup per CU (LDS 155 KB at
+// d = 10: covmat_empirical and theta_mean as [element][lane] per group).
+//
+// What is done differently from the reference, results equal up to rounding:
+//   * chol(s^2 Sigma) = s chol(Sigma): the kernel keeps the UNSCALED factor R (chol(covmat) in the size
+//     phase, chol(covmat_empirical) in the shape phase) and the scale s apart, so the size phase needs
+//     no factorization at all (the reference refactors s^2 covmat every iteration, :129,153) and the
+//     shape phase factors covmat_empirical itself; the proposal is theta + s (Y R);
+//   * update_sigma (:43) as C (i-1)/i + ((i-1)/i^2 r_a) r_b, one FMA per element; the factorization of
+//     iteration i+1 consumes each updated element from the register it is in (loop rotated);
+//   * mvrnorm_pdf (:48-64) from det = (s^d prod diag R)^2 and v^T Sigma^-1 v = |Y|^2, still evaluated
+//     as log(rootTerm exp(-q/2)), added and subtracted, so the (la + p) - p rounding and the NaN
+//     reject path survive;
+//   * the Gaussian target -0.5 v^T H v is summed over the upper triangle of H (55 instead of 100 terms).
+// The acceptance-rate recurrences (:188-207) and the phase tests (:117,131) use the reference's
+// exact operation sequence (no FMA contraction): they feed discrete decisions.
+#include "common.h"
+#include "philox.h"
+#include "targets.h"
+
+namespace mcmc {
+
+// target parameters as the kernel wants them
+template <int KIND, int D>
+struct PackedTarget;
+
+// Gaussian by precision: m[D], diag(H)[D], then for j = 1..D-1, i < j: H_ij + H_ji at D + D + j(j-1)/2 + i
+template <int D>
+struct PackedTarget<MCMC_TARGET_GAUSSIAN_PREC, D> {
+    static constexpr int NP = 2 * D + D * (D - 1) / 2;
+    static void pack(const std::vector<double> &tp, double *out)
+    {
+        for (int k = 0; k < D; ++k) out[k] = tp[k];
+        const double *H = tp.data() + D; // column-major
+        for (int j = 0; j < D; ++j) {
+            out[D + j] = H[j * D + j];
+            for (int i = 0; i < j; ++i) out[2 * D + j * (j - 1) / 2 + i] = H[j * D + i] + H[i * D + j];
+        }
+    }
+    // -0.5 sum_j v_j (H_jj v_j + sum_{i<j} (H_ij + H_ji) v_i)
+    __device__ static __forceinline__ double eval(const double (&x)[D], const double *p)
+    {
+        double v[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) v[k] = x[k] - p[k];
+        double q = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            double g = p[D + j] * v[j];
+#pragma unroll
+            for (int i = 0; i < j; ++i) g += p[2 * D + j * (j - 1) / 2 + i] * v[i];
+            q += v[j] * g;
+        }
+        return -0.5 * q;
+    }
+};
+
+struct PackedPrmView {
+    const double *p;
+    __device__ __forceinline__ double operator[](int i) const { return p[i]; }
+};
+
+template <>
+struct PackedTarget<MCMC_TARGET_GOLDSTEIN_PRICE, 2> {
+    static constexpr int NP = 0;
+    static void pack(const std::vector<double> &, double *) {}
+    __device__ static __forceinline__ double eval(const double (&x)[2], const double *p)
+    {
+        return Target<MCMC_TARGET_GOLDSTEIN_PRICE, 2>::eval(x, PackedPrmView{p});
+    }
+};
+
+template <>
+struct PackedTarget<MCMC_TARGET_BANANA, 2> {
+    static constexpr int NP = 1;
+    static void pack(const std::vector<double> &tp, double *out) { out[0] = tp[0]; }
+    __device__ static __forceinline__ double eval(const double (&x)[2], const double *p)
+    {
+        return Target<MCMC_TARGET_BANANA, 2>::eval(x, PackedPrmView{p});
+    }
+};
+
+constexpr int kPairGroups = 4; // chain groups (of 64) per workgroup = sampler waves = generator waves
+
+// parameter block in HBM (doubles): covdiag[D] tprm[NP] | init[D] R0[T] prodR0
+// the first SH doubles are staged in LDS; the rest is read once (or on a rare phase change)
+template <int D, int KIND, bool MOMENTS>
+struct PairLayout {
+    static constexpr int T = D * (D + 1) / 2;
+    static constexpr int NP = PackedTarget<KIND, D>::NP;
+    static constexpr int COVD = 0, TPRM = D;
+    static constexpr int SH = (D + NP + 1) & ~1;
+    static constexpr int INIT = SH, R0 = SH + D, PROD0 = SH + D + T;
+    static constexpr int TOTAL = PROD0 + 1;
+    static constexpr int CT = MOMENTS ? T : 0;      // covmat_empirical as [e][lane]
+    static constexpr int MT = MOMENTS ? D : 0;      // theta_mean as [k][lane]
+    static constexpr int HAND = D + 2;              // Y[D], exp(-q/2), log A as [e][lane]
+    static constexpr int GROUP = (CT + MT + HAND) * 64 + 8; // + wave-uniform scalars of the iteration
+    static constexpr int LDS_DOUBLES = SH + kPairGroups * GROUP;
+};
+
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt,
+// i.e. it would hold the sampler until its trace stores to HBM are acknowledged, every iteration.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// x^D by repeated squaring (D is a compile-time constant)
+template <int D>
+__device__ __forceinline__ double powi(double x)
+{
+    if constexpr (D == 1) {
+        return x;
+    } else if constexpr (D % 2 == 0) {
+        const double h = powi<D / 2>(x);
+        return h * h;
+    } else {
+        return x * powi<D - 1>(x);
+    }
+}
+
+template <int D, int KIND, bool MOMENTS>
+__global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmArgs a, const double *__restrict__ prm)
+{
+    using Lay = PairLayout<D, KIND, MOMENTS>;
+    constexpr int T = Lay::T;
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool generator = wave >= kPairGroups;
+    const int group = wave & (kPairGroups - 1);
+    const int64_t c = ((int64_t)blockIdx.x * kPairGroups + group) * 64 + lane;
+    const int64_t n = a.n_chains;
+    const bool live = c < n;
+    const int64_t cc = live ? c : n - 1; // lanes past the end shadow the last chain and store nothing
+    const uint64_t gchain = (uint64_t)(a.chain_offset + cc);
+    const int n_iter = a.n_iterations;
+
+    for (int e = tid; e < Lay::SH; e += 128 * kPairGroups) lds[e] = prm[e];
+    __syncthreads();
+    const double *const sh = lds;
+    double *const G0 = lds + Lay::SH + group * Lay::GROUP;
+    double *const Cl = G0 + lane;                            // covmat_empirical element e at Cl[e * 64]
+    double *const Ml = G0 + Lay::CT * 64 + lane;             // theta_mean element k at Ml[k * 64]
+    double *const Hl = G0 + (Lay::CT + Lay::MT) * 64 + lane; // hand-over slot e at Hl[e * 64]
+    double *const Us = G0 + (Lay::CT + Lay::MT + Lay::HAND) * 64; // (i-1)/i, (i-1)/i^2, 1/i of the iteration handed over
+
+    // Both roles pass the same two barriers per iteration i = 1..n: "hand-over buffer holds iteration i"
+    // and "buffer read, free again"; each role runs its own loop so that neither's registers are live in
+    // the other's code.
+    if (generator) {
+        const PhiloxKey key(a.seed);
+        for (int i = 1; i <= n_iter; ++i) {
+            // draws of iteration i, while the sampler works on iteration i - 1
+            double Y[D];
+#pragma unroll
+            for (int b = 0; 2 * b < D; ++b) {
+                double z0, z1;
+                philox_normal2(key, gchain, (uint32_t)i, TAG_RWM_NORMAL, (uint32_t)b, z0, z1);
+                Y[2 * b] = z0;
+                if (2 * b + 1 < D) Y[2 * b + 1] = z1;
+            }
+            double q = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) q += Y[j] * Y[j];
+            const double eq = fm_exp(-0.5 * q);
+            double A, u1;
+            philox_uniform2(key, gchain, (uint32_t)i, TAG_RWM_UNIFORM, 0u, A, u1);
+            const double logA = fm_log<true>(A);
+            const double di = (double)i;
+            const double sfac = (di - 1.0) / di;
+#pragma unroll
+            for (int k = 0; k < D; ++k) Hl[k * 64] = Y[k];
+            Hl[D * 64] = eq;
+            Hl[(D + 1) * 64] = logA;
+            if (lane == 0) {
+                Us[0] = sfac;
+                Us[1] = sfac / di;
+                Us[2] = 1.0 / di;
+            }
+            lds_barrier(); // hand-over buffer holds iteration i
+            lds_barrier(); // sampler has read it
+        }
+        return;
+    }
+
+    // ---- sampler -----------------------------------------------------------------------------------
+    const int ass = a.adapt_size_start, ashs = a.adapt_shape_start;
+    const int window = a.acceptance_window;
+    const double w = a.acceptance_rate_weight;
+    const double *const tp = sh + Lay::TPRM;
+    double theta[D], R[T]; // R: unscaled upper factor, R^T R = covmat (size phase) or covmat_empirical (shape phase)
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        theta[k] = a.d_init ? a.d_init[(int64_t)k * n + cc] : prm[Lay::INIT + k];
+        if (MOMENTS) Ml[k * 64] = theta[k];
+    }
+#pragma unroll
+    for (int e = 0; e < T; ++e) {
+        if (MOMENTS) Cl[e * 64] = 0.0;
+        R[e] = prm[Lay::R0 + e];
+    }
+    double prodR = prm[Lay::PROD0]; // product of diag(R)
+    bool base_emp = false;          // R holds chol(covmat_empirical)
+    double s_eff = 1.0;             // scale of covmat_proposal = s_eff^2 R^T R
+    double rootTerm, sq_unused;
+    fm_sqrt_rsq(a.twopi_pow_d * (prodR * prodR), sq_unused, rootTerm);
+    double t_cur = PackedTarget<KIND, D>::eval(theta, tp);
+    double rate = 0.0, scaling_sd = 1.0, scaling_multiplier = 1.0;
+    uint64_t win_bits = 0;
+    int win_len = 0;
+    int32_t status = MCMC_CHAIN_OK, n_shape = 0;
+    bool dead = false;
+    int next_keep = a.thin; // next iteration whose state is stored
+    int64_t t_kept = 0;
+
+    // i = 0 is the prologue: adaptation (and factorization) for iteration 1 only
+    for (int i = 0; i <= n_iter; ++i) {
+        double sfac = 0.0, bfac = 0.0, inv_i = 1.0;
+        if (i > 0) {
+            double Y[D];
+            lds_barrier(); // hand-over buffer holds iteration i
+#pragma unroll
+            for (int k = 0; k < D; ++k) Y[k] = Hl[k * 64];
+            const double eq = Hl[D * 64];
+            const double logA = Hl[(D + 1) * 64];
+            sfac = Us[0];
+            bfac = Us[1];
+            inv_i = Us[2];
+            lds_barrier(); // buffer free again
+
+            // ---- proposal theta + Y chol(covmat_proposal) = theta + s (Y R) (:149-154) -----------
+            double prop[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k <= j; ++k) s += Y[k] * R[tri(k, j)];
+                prop[j] = theta[j] + s_eff * s;
+            }
+            // ---- target and Metropolis-Hastings log ratio (:157-171) ----------------------------
+            const double t_prop = PackedTarget<KIND, D>::eval(prop, tp);
+            double la;
+            if (!isfinite(t_prop)) {
+                la = -__builtin_inf();
+            } else {
+                la = t_prop - t_cur;
+                const double p = fm_log<true>(rootTerm * eq); // mvrnorm_pdf, both directions (:48-64)
+                la = add_rn(la, p);
+                la = add_rn(la, -p);
+            }
+            // ---- accept / reject (:174-182) ------------------------------------------------------
+            const bool accept = logA < la;
+            if (accept) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) theta[k] = prop[k];
+                t_cur = t_prop;
+            }
+            // ---- trace (:185) -------------------------------------------------------------------
+            if (i == next_keep) {
+                if (a.d_trace && live) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) a.d_trace[(t_kept * D + k) * n + c] = theta[k];
+                }
+                next_keep += a.thin;
+                ++t_kept;
+            }
+            // ---- acceptance rate (:188-207): the reference's exact operation sequence ------------
+            const double acc = accept ? 1.0 : 0.0;
+            const double di = (double)i;
+            if (i == 1) {
+                rate = acc;
+            } else if (w == 0) {
+                if (window == 0) {
+                    rate = add_rn(rate, div_rn(add_rn(acc, -rate), di));
+                } else {
+                    win_bits = (win_bits << 1) | (accept ? 1ull : 0ull);
+                    if (win_len < window) ++win_len;
+                    const uint64_t m = (win_len >= 64) ? ~0ull : ((1ull << win_len) - 1ull);
+                    rate = div_rn((double)__popcll(win_bits & m), (double)win_len);
+                }
+            } else {
+                rate = add_rn(mul_rn(rate, 1 - w), mul_rn(acc, w));
+            }
+        }
+
+        // ---- adaptation of covmat_proposal for iteration i + 1 (:117-139) -----------------------
+        bool rescale = false, refactor = false;
+        if (i < n_iter) {
+            const int in = i + 1;
+            const double din = (double)in;
+            if (ass != 0 && in >= ass && (ashs == 0 || mul_rn(rate, din) < (double)ashs)) {
+                scaling_multiplier = fm_exp(a.d_cool_pow[in] * (rate - 0.234));
+                scaling_sd = mul_rn(scaling_sd, scaling_multiplier);
+                scaling_sd = (a.max_scaling_sd < scaling_sd) ? a.max_scaling_sd : scaling_sd; // std::min
+                const double s2 = mul_rn(scaling_sd, scaling_sd);
+                bool any_small = false;
+#pragma unroll
+                for (int k = 0; k < D; ++k) any_small |= (mul_rn(s2, sh[Lay::COVD + k]) < 2E-16);
+                rescale = !any_small && !dead; // covmat_proposal = scaling_sd^2 covmat (:129)
+            } else if (ashs != 0 && mul_rn(rate, din) >= (double)ashs) {
+                scaling_sd = a.shape_scaling_sd;
+                refactor = !dead; // covmat_proposal = scaling_sd^2 covmat_empirical (:138)
+                ++n_shape;
+            }
+        }
+        if (rescale) {
+            if (base_emp) { // back from the shape phase: the factor of covmat again
+#pragma unroll
+                for (int e = 0; e < T; ++e) R[e] = prm[Lay::R0 + e];
+                prodR = prm[Lay::PROD0];
+                base_emp = false;
+            }
+            s_eff = scaling_sd;
+        }
+
+        // ---- update_sigma / mean of iteration i (:210-214, :42-45) fused with R = chol(covmat_empirical)
+        //      for iteration i + 1 (:153) ------------------------------------------------------------
+        if constexpr (MOMENTS) {
+            double res[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const double mk = Ml[k * 64];
+                res[k] = theta[k] - mk; // i = 0: exactly zero, C stays 0
+                Ml[k * 64] = mk + res[k] * inv_i;
+            }
+            bool ok = true;
+            double prod = 1.0;
+            double rinv[D];
+#pragma unroll
+            for (int cl = 0; cl < D; ++cl) {
+                double col[D];
+                const double bc = bfac * res[cl];
+#pragma unroll
+                for (int r = 0; r <= cl; ++r) {
+                    const double v = fma(Cl[tri(r, cl) * 64], sfac, bc * res[r]);
+                    Cl[tri(r, cl) * 64] = v;
+                    col[r] = v;
+                }
+                if (refactor) {
+#pragma unroll
+                    for (int r = 0; r < cl; ++r) {
+                        double s = col[r];
+#pragma unroll
+                        for (int m = 0; m < r; ++m) s -= R[tri(m, r)] * R[tri(m, cl)];
+                        R[tri(r, cl)] = s * rinv[r];
+                    }
+                    double ajj = col[cl];
+#pragma unroll
+                    for (int m = 0; m < cl; ++m) ajj -= R[tri(m, cl)] * R[tri(m, cl)];
+                    ok = ok && (ajj > 0.0);
+                    double rjj;
+                    fm_sqrt_rsq(ajj, rjj, rinv[cl]);
+                    R[tri(cl, cl)] = rjj;
+                    prod *= rjj;
+                }
+            }
+            if (refactor) {
+                prodR = prod;
+                base_emp = true;
+                s_eff = scaling_sd;
+                if (!ok) { // arma::chol throws here; the chain stops and reports where
+                    dead = true;
+                    status = ((i + 1) << 4) | MCMC_CHAIN_CHOL_FAILED;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) theta[k] = __builtin_nan("");
+                }
+            }
+        }
+        if (rescale || refactor) { // 1 / sqrt((2 pi)^d det(covmat_proposal)) (:56)
+            const double dt = powi<D>(s_eff) * prodR;
+            double sq;
+            fm_sqrt_rsq(a.twopi_pow_d * (dt * dt), sq, rootTerm);
+        }
+    }
+
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            if (a.d_final_theta) a.d_final_theta[(int64_t)k * n + c] = theta[k];
+            if (MOMENTS && a.d_final_mean) a.d_final_mean[(int64_t)k * n + c] = Ml[k * 64];
+        }
+        if (MOMENTS && a.d_final_cov) {
+#pragma unroll
+            for (int cl = 0; cl < D; ++cl) {
+#pragma unroll
+                for (int r = 0; r < D; ++r)
+                    a.d_final_cov[(int64_t)(cl * D + r) * n + c] = Cl[(r <= cl ? tri(r, cl) : tri(cl, r)) * 64];
+            }
+        }
+        if (a.d_acceptance_rate) a.d_acceptance_rate[c] = rate;
+        if (a.d_status) a.d_status[c] = status;
+        if (a.d_shape_iterations) a.d_shape_iterations[c] = n_shape;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+template <int D, int KIND>
+static int launch_rwm_pair_dk(const RwmArgs &a, const RwmParams &p, hipStream_t s)
+{
+    using Lay = PairLayout<D, KIND, true>;
+    if ((int)p.tparams.size() != target_param_count(KIND, D))
+        return set_error(MCMC_E_BAD_ARG, "target kind %d with d=%d needs %d parameters, got %d", KIND, D,
+                         target_param_count(KIND, D), (int)p.tparams.size());
+    std::vector<double> blob(Lay::TOTAL, 0.0);
+    double prod0 = 1.0;
+    for (int k = 0; k < D; ++k) {
+        blob[Lay::COVD + k] = p.cov_packed[tri(k, k)];
+        blob[Lay::INIT + k] = p.init[k];
+        prod0 *= p.R0_packed[tri(k, k)];
+    }
+    PackedTarget<KIND, D>::pack(p.tparams, blob.data() + Lay::TPRM);
+    for (int e = 0; e < Lay::T; ++e) blob[Lay::R0 + e] = p.R0_packed[e];
+    blob[Lay::PROD0] = prod0;
+    double *d_prm = nullptr;
+    MCMC_HIP_CHECK(hipMallocAsync((void **)&d_prm, blob.size() * sizeof(double), s));
+    MCMC_HIP_CHECK(hipMemcpyAsync(d_prm, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    MCMC_HIP_CHECK(hipStreamSynchronize(s)); // blob is a local: do not let the copy outlive it
+    const int64_t grid = (a.n_chains + 64 * kPairGroups - 1) / (64 * kPairGroups);
+    const bool moments = a.adapt_shape_start != 0 || a.d_final_mean || a.d_final_cov;
+    hipError_t e0 = hipSuccess;
+    auto go = [&](auto kern, size_t lds_doubles) {
+        const size_t ldsb = lds_doubles * sizeof(double);
+        e0 = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+        if (e0 == hipSuccess)
+            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(128 * kPairGroups), ldsb, s, a, (const double *)d_prm);
+    };
+    if (moments)
+        go(rwm_pair_kernel<D, KIND, true>, PairLayout<D, KIND, true>::LDS_DOUBLES);
+    else
+        go(rwm_pair_kernel<D, KIND, false>, PairLayout<D, KIND, false>::LDS_DOUBLES);
+    hipError_t e1 = hipGetLastError();
+    hipError_t e2 = hipFreeAsync(d_prm, s);
+    if (e0 != hipSuccess) return set_error(MCMC_E_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e0));
+    if (e1 != hipSuccess) return set_error(MCMC_E_HIP, "rwm_pair_kernel launch failed: %s", hipGetErrorString(e1));
+    if (e2 != hipSuccess) return set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e2));
+    return MCMC_OK;
+}
+
+bool rwm_pair_serves(const RwmArgs &a)
+{
+    const bool full = a.d_Z || a.d_sigma_trace || a.d_accepted || a.d_log_acceptance || a.d_log_A || a.d_scaling_sd ||
+                      a.d_scaling_multiplier || a.d_rate_trace;
+    return !full && a.d >= 1 && a.d <= kMaxPairDimRwm;
+}
+
+int launch_rwm_pair(const RwmArgs &a, const RwmParams &p, hipStream_t s)
+{
+    if (!rwm_pair_serves(a))
+        return set_error(MCMC_E_UNSUPPORTED, "paired-wave kernel: Philox streams, no per-iteration diagnostics, d <= %d",
+                         kMaxPairDimRwm);
+    if (p.target_kind == MCMC_TARGET_GOLDSTEIN_PRICE) {
+        if (a.d != 2) return set_error(MCMC_E_BAD_ARG, "Goldstein-Price target is 2-dimensional (d=%d)", a.d);
+        return launch_rwm_pair_dk<2, MCMC_TARGET_GOLDSTEIN_PRICE>(a, p, s);
+    }
+    if (p.target_kind == MCMC_TARGET_BANANA) {
+        if (a.d != 2) return set_error(MCMC_E_BAD_ARG, "banana target is 2-dimensional (d=%d)", a.d);
+        return launch_rwm_pair_dk<2, MCMC_TARGET_BANANA>(a, p, s);
+    }
+    if (p.target_kind != MCMC_TARGET_GAUSSIAN_PREC)
+        return set_error(MCMC_E_BAD_ARG, "unknown target kind %d", p.target_kind);
+    switch (a.d) {
+#define MCMC_CASE(D) \
+    case D: return launch_rwm_pair_dk<D, MCMC_TARGET_GAUSSIAN_PREC>(a, p, s);
+        MCMC_CASE(1) MCMC_CASE(2) MCMC_CASE(3) MCMC_CASE(4) MCMC_CASE(5) MCMC_CASE(6)
+        MCMC_CASE(7) MCMC_CASE(8) MCMC_CASE(9) MCMC_CASE(10)
+#undef MCMC_CASE
+    default: return set_error(MCMC_E_UNSUPPORTED, "paired-wave kernel: d=%d outside 1..%d", a.d, kMaxPairDimRwm);
+    }
+}
+
+} // namespace mcmc

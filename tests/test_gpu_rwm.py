@@ -314,3 +314,74 @@ def test_block_kernel_philox_sharding_and_failure(cuda, oracle):
     out = mcmc_amd.adapt_rwm_batch(tgt, 3, np.zeros(d), 0.05 * np.eye(d), 100, 0, 0.0, 0, 1, seed=5, kernel="block")
     st = out["status"].cpu().numpy()
     assert np.all((st & 15) == mcmc_amd.MCMC_CHAIN_CHOL_FAILED) and np.all((st >> 4) >= 2)
+
+
+@pytest.mark.parametrize("d,ass,ashs,w,win", [(10, 30, 90, 0.0, 0), (4, 20, 60, 0.05, 0), (7, 25, 0, 0.0, 20), (3, 0, 0, 0.0, 0),
+                                              (2, 10, 40, 0.0, 0)])
+def test_paired_wave_kernel_matches_lane_kernel_and_oracle(cuda, oracle, d, ass, ashs, w, win):
+    """The production kernel for d <= 10 (sampler + generator wavefront per 64 chains, Philox streams)
+    against the one-wave kernel on the same run and against the oracle fed with the streams
+    mcmc_rwm_streams reports (adaptMCMC_source.cpp:108-216)."""
+    import mcmc_amd
+
+    nc, n = 200, 500
+    Sig, H = _gauss(d, 0.8)
+    tgt = mcmc_amd.Target.gaussian(0.5 * np.ones(d), H)
+    init = mcmc_amd.init_normal(3, nc, np.zeros(d), 1.5, chain_offset=77)
+    kw = dict(seed=11, chain_offset=77)
+    pair = mcmc_amd.adapt_rwm_batch(tgt, nc, init, np.eye(d), n, ass, w, win, ashs, kernel="pair", **kw)
+    lane = mcmc_amd.adapt_rwm_batch(tgt, nc, init, np.eye(d), n, ass, w, win, ashs, kernel="lane", **kw)
+    auto = mcmc_amd.adapt_rwm_batch(tgt, nc, init, np.eye(d), n, ass, w, win, ashs, **kw)
+    cuda.cuda.synchronize()
+    assert np.all(pair["status"].cpu().numpy() == 0)
+    assert cuda.equal(auto["theta_trace"], pair["theta_trace"])  # auto picks the paired-wave kernel here
+    tp, tl = pair["theta_trace"].cpu().numpy(), lane["theta_trace"].cpu().numpy()
+    assert _rel(tp, tl) < RTOL
+    np.testing.assert_array_equal(pair["acceptance_rate"].cpu().numpy(), lane["acceptance_rate"].cpu().numpy())
+    for key in ("final_theta", "final_mean", "final_cov"):
+        np.testing.assert_allclose(pair[key].cpu().numpy(), lane[key].cpu().numpy(), rtol=1e-11, atol=1e-13)
+    Z, U = mcmc_amd.rwm_streams(11, nc, n, d, chain_offset=77)
+    Z, U, x0 = Z.cpu().numpy(), U.cpu().numpy(), init.cpu().numpy()
+    for c in (0, 63, 64, 199):
+        ref = oracle.adaptMCMC(oracle.gaussian_target(0.5 * np.ones(d), H), x0[:, c], np.eye(d), n, ass, w, win, ashs,
+                               Z[:, :, c], U[:, c], diagnostics=True)
+        assert _rel(tp[:, :, c], ref["theta_trace"]) < RTOL
+        assert pair["acceptance_rate"].cpu().numpy()[c] == ref["acceptance_rate"]
+        np.testing.assert_allclose(pair["final_cov"].cpu().numpy()[:, c].reshape(d, d, order="F"),
+                                   ref["sigma_empirical"][:, :, -1], rtol=1e-9, atol=1e-12)
+
+
+def test_paired_wave_kernel_targets_thinning_and_failure(cuda, oracle):
+    import mcmc_amd
+
+    # 2-D targets of adaptMCMC_analysis.R through the paired-wave kernel, replayed through the oracle
+    for tgt, otgt, x0, ass, ashs in ((mcmc_amd.Target.banana(0.03), oracle.banana_target(0.03), [10.0, 10.0], 10, 20),
+                                     (mcmc_amd.Target.goldstein_price(), oracle.goldstein_price_target(), [1.0, 1.0], 100, 150)):
+        n, nc = 600, 70
+        out = mcmc_amd.adapt_rwm_batch(tgt, nc, x0, np.eye(2), n, ass, 0.0, 0, ashs, seed=9, kernel="pair")
+        Z, U = mcmc_amd.rwm_streams(9, nc, n, 2)
+        for c in (0, 69):
+            ref = oracle.adaptMCMC(otgt, x0, np.eye(2), n, ass, 0.0, 0, ashs, Z.cpu().numpy()[:, :, c], U.cpu().numpy()[:, c],
+                                   store_sigma=False)
+            assert _rel(out["theta_trace"].cpu().numpy()[:, :, c], ref["theta_trace"]) < RTOL
+    # thinning and sharding
+    d = 6
+    Sig, H = _gauss(d, 0.6)
+    tgt = mcmc_amd.Target.gaussian(np.zeros(d), H)
+    kw = dict(adapt_size_start=20, adapt_shape_start=60, seed=5, kernel="pair")
+    whole = mcmc_amd.adapt_rwm_batch(tgt, 160, np.zeros(d), np.eye(d), 300, **kw)["theta_trace"]
+    part = mcmc_amd.adapt_rwm_batch(tgt, 96, np.zeros(d), np.eye(d), 300, chain_offset=64, **kw)["theta_trace"]
+    assert cuda.equal(whole[:, :, 64:], part)
+    thin = mcmc_amd.adapt_rwm_batch(tgt, 160, np.zeros(d), np.eye(d), 300, thin=7, **kw)["theta_trace"]
+    assert thin.shape[0] == 42 and cuda.equal(thin, whole[6::7][:42])
+    # rank-deficient covmat_empirical: same failure iteration as the one-wave kernel (adaptMCMC_source.cpp:153)
+    a = mcmc_amd.adapt_rwm_batch(tgt, 66, np.zeros(d), np.eye(d), 100, 0, 0.0, 0, 1, seed=5, kernel="pair")
+    b = mcmc_amd.adapt_rwm_batch(tgt, 66, np.zeros(d), np.eye(d), 100, 0, 0.0, 0, 1, seed=5, kernel="lane")
+    sa, sb = a["status"].cpu().numpy(), b["status"].cpu().numpy()
+    assert np.all((sa & 15) == mcmc_amd.MCMC_CHAIN_CHOL_FAILED)
+    np.testing.assert_array_equal(sa, sb)
+    ta, tb = a["theta_trace"].cpu().numpy(), b["theta_trace"].cpu().numpy()
+    np.testing.assert_array_equal(np.isnan(ta), np.isnan(tb))
+    # requests the paired-wave kernel does not serve are refused, not silently rerouted
+    with pytest.raises(mcmc_amd.McmcError):
+        mcmc_amd.adapt_rwm_batch(tgt, 4, np.zeros(d), np.eye(d), 10, diagnostics=True, kernel="pair")
