@@ -17,6 +17,11 @@
 // Scalars of the chain (acceptance rate, scaling_sd, cached target value, ...) are replicated in
 // every thread, so decisions are taken without a broadcast.
 //
+// chol(s^2 Sigma) = s chol(Sigma): R in LDS is the UNSCALED factor -- chol(covmat) while the size phase
+// runs, chol(covmat_empirical) in the shape phase -- and the scale s is kept apart (the proposal is
+// theta + s (Y R)).  The size phase therefore needs no factorization (the reference refactors
+// scaling_sd^2 covmat every iteration, adaptMCMC_source.cpp:129,153: d^3/3 flops for the same matrix).
+//
 // The factorization is the right-looking (outer-product) Cholesky with the trailing matrix held in
 // registers: at step j the owners of row j publish it (unscaled, pivot included) in a double-buffered
 // LDS row, ONE barrier, then every thread scales the 2 NT entries it needs by 1/sqrt(pivot) and
@@ -113,6 +118,15 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
     };
 
     double rootTerm = prm[L.root0()];
+    double prodR = 1.0; // product of diag(R)
+    double min_var = prm[L.cov()]; // smallest diagonal entry of covmat: decides the test at :126 (rounding is monotone)
+    for (int k = 0; k < d; ++k) {
+        prodR *= prm[L.r0() + tri(k, k)];
+        min_var = fmin(min_var, prm[L.cov() + tri(k, k)]);
+    }
+    const double prodR0 = prodR;
+    bool base_emp = false; // R holds chol(covmat_empirical)
+    double s_eff = 1.0;    // covmat_proposal = s_eff^2 R^T R
     double t_cur = target(th);
     double rate = 0.0, scaling_sd = 1.0, scaling_multiplier = 1.0;
     uint64_t win_bits = 0;
@@ -123,21 +137,17 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
     for (int i = 1; i <= a.n_iterations; ++i) {
         const double di = (double)i;
         // ---- adaptation of covmat_proposal (adaptMCMC_source.cpp:117-139), replicated ---------------
-        bool dirty = false, use_emp = false;
-        double s2 = 0.0;
+        bool rescale = false, refactor = false;
         if (ass != 0 && i >= ass && (ashs == 0 || mul_rn(rate, di) < (double)ashs)) {
-            scaling_multiplier = exp(a.d_cool_pow[i] * (rate - 0.234));
+            scaling_multiplier = fm_exp(a.d_cool_pow[i] * (rate - 0.234));
             scaling_sd = mul_rn(scaling_sd, scaling_multiplier);
             scaling_sd = (a.max_scaling_sd < scaling_sd) ? a.max_scaling_sd : scaling_sd;
-            s2 = mul_rn(scaling_sd, scaling_sd);
-            bool any_small = false;
-            for (int k = 0; k < d; ++k) any_small |= (mul_rn(s2, prm[L.cov() + tri(k, k)]) < 2E-16);
-            dirty = !any_small;
+            const double s2 = mul_rn(scaling_sd, scaling_sd);
+            const bool any_small = mul_rn(s2, min_var) < 2E-16;
+            rescale = !any_small && !dead; // covmat_proposal = scaling_sd^2 covmat (:129)
         } else if (ashs != 0 && mul_rn(rate, di) >= (double)ashs) {
             scaling_sd = a.shape_scaling_sd;
-            s2 = mul_rn(scaling_sd, scaling_sd);
-            dirty = true;
-            use_emp = true;
+            refactor = !dead; // covmat_proposal = scaling_sd^2 covmat_empirical (:138)
             ++n_shape;
         }
         if (FULL && tid == 0) {
@@ -146,17 +156,19 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
         }
 
         // ---- R = chol(covmat_proposal) when it was assigned (:153) --------------------------------
-        if (dirty && !dead) { // uniform over the workgroup
-#pragma unroll
-            for (int bb = 0; bb < NT; ++bb) {
-#pragma unroll
-                for (int aa = 0; aa <= bb; ++aa) {
-                    const int ii = 16 * aa + ti, kk = 16 * bb + tk;
-                    double src = Ct[blk(aa, bb)];
-                    if (!use_emp) src = (ii <= kk && kk < d) ? prm[L.cov() + tri(ii, kk)] : 0.0;
-                    At[blk(aa, bb)] = s2 * src;
-                }
+        if (rescale) { // uniform over the workgroup
+            if (base_emp) { // back from the shape phase: the factor of covmat again
+                __syncthreads();
+                for (int e = tid; e < T; e += kBlockThreads) A[e] = prm[L.r0() + e];
+                __syncthreads();
+                prodR = prodR0;
+                base_emp = false;
             }
+            s_eff = scaling_sd;
+        }
+        if (refactor) { // uniform over the workgroup
+#pragma unroll
+            for (int q = 0; q < NB; ++q) At[q] = Ct[q];
             bool ok = true;
             double prod = 1.0;
 #pragma unroll
@@ -201,13 +213,24 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
                 }
             }
             __syncthreads();
-            rootTerm = 1.0 / sqrt(a.twopi_pow_d * (prod * prod));
+            prodR = prod;
+            base_emp = true;
+            s_eff = scaling_sd;
             if (!ok) { // arma::chol throws here; the chain stops and reports where
                 dead = true;
                 status = (i << 4) | MCMC_CHAIN_CHOL_FAILED;
                 if (tid < d) th[tid] = __builtin_nan("");
                 __syncthreads();
             }
+        }
+        if (rescale || refactor) { // 1 / sqrt((2 pi)^d det(covmat_proposal)) (:56)
+            double sp = 1.0, b = s_eff;
+            for (int e = d; e > 0; e >>= 1) { // s_eff^d by repeated squaring
+                if (e & 1) sp *= b;
+                b *= b;
+            }
+            const double dt = sp * prodR;
+            rootTerm = 1.0 / sqrt(a.twopi_pow_d * (dt * dt));
         }
 
         // ---- draws: d normals, then one uniform (:149-152,174) ----------------------------------------
@@ -234,7 +257,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
             const double *col = A + tri(0, tid);
             double s = 0.0;
             for (int k = 0; k <= tid; ++k) s += Y[k] * col[k];
-            pr[tid] = th[tid] + s;
+            pr[tid] = th[tid] + s_eff * s;
         }
         double q = 0.0;
         for (int k = 0; k < d; ++k) q += Y[k] * Y[k];
@@ -248,7 +271,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
             la = -__builtin_inf();
         } else {
             la = t_prop - t_cur;
-            const double p = fm_log<true>(rootTerm * exp(-0.5 * q));
+            const double p = fm_log<true>(rootTerm * fm_exp(-0.5 * q));
             la = add_rn(la, p);
             la = add_rn(la, -p);
         }
@@ -289,9 +312,9 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
 
         // ---- running mean / covariance (:210-214, update_sigma :42-45) ----------------------------------
         if (need_moments) {
-            const double im1 = di - 1.0;
-            const double sfac = im1 / di;
             const double inv_i = 1.0 / di;
+            const double sfac = (di - 1.0) * inv_i; // update_sigma (:43) as C (i-1)/i + ((i-1)/i^2 r_a) r_b
+            const double bfac = sfac * inv_i;
             if (tid < d) {
                 const double mk = mn[tid];
                 const double r = th[tid] - mk;
@@ -303,14 +326,14 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
             double rv[NT], cv[NT];
 #pragma unroll
             for (int x = 0; x < NT; ++x) {
-                rv[x] = (16 * x + ti < d) ? sfac * v[16 * x + ti] : 0.0;
+                rv[x] = (16 * x + ti < d) ? bfac * v[16 * x + ti] : 0.0;
                 cv[x] = (16 * x + tk < d) ? v[16 * x + tk] : 0.0;
             }
 #pragma unroll
             for (int bb = 0; bb < NT; ++bb) {
 #pragma unroll
                 for (int aa = 0; aa <= bb; ++aa) {
-                    const double val = (Ct[blk(aa, bb)] * im1 + rv[aa] * cv[bb]) * inv_i;
+                    const double val = fma(Ct[blk(aa, bb)], sfac, rv[aa] * cv[bb]);
                     Ct[blk(aa, bb)] = val;
                     if (sig) {
                         const int r = 16 * aa + ti, cl = 16 * bb + tk;

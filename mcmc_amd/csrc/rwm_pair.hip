@@ -53,12 +53,11 @@ struct PackedTarget<MCMC_TARGET_GAUSSIAN_PREC, D> {
             for (int i = 0; i < j; ++i) out[2 * D + j * (j - 1) / 2 + i] = H[j * D + i] + H[i * D + j];
         }
     }
-    // -0.5 sum_j v_j (H_jj v_j + sum_{i<j} (H_ij + H_ji) v_i)
-    __device__ static __forceinline__ double eval(const double (&x)[D], const double *p)
+    // The sampler keeps the chain state CENTRED, v = theta - m (one subtraction at the start, one addition
+    // per stored value), so the target reads the state as it is: -0.5 sum_j v_j (H_jj v_j + sum_{i<j} (H_ij + H_ji) v_i)
+    static constexpr bool CENTRED = true;
+    __device__ static __forceinline__ double eval(const double (&v)[D], const double *p)
     {
-        double v[D];
-#pragma unroll
-        for (int k = 0; k < D; ++k) v[k] = x[k] - p[k];
         double q = 0.0;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
@@ -79,6 +78,7 @@ struct PackedPrmView {
 template <>
 struct PackedTarget<MCMC_TARGET_GOLDSTEIN_PRICE, 2> {
     static constexpr int NP = 0;
+    static constexpr bool CENTRED = false;
     static void pack(const std::vector<double> &, double *) {}
     __device__ static __forceinline__ double eval(const double (&x)[2], const double *p)
     {
@@ -89,6 +89,7 @@ struct PackedTarget<MCMC_TARGET_GOLDSTEIN_PRICE, 2> {
 template <>
 struct PackedTarget<MCMC_TARGET_BANANA, 2> {
     static constexpr int NP = 1;
+    static constexpr bool CENTRED = false;
     static void pack(const std::vector<double> &tp, double *out) { out[0] = tp[0]; }
     __device__ static __forceinline__ double eval(const double (&x)[2], const double *p)
     {
@@ -120,6 +121,14 @@ struct PairLayout {
 __device__ __forceinline__ void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// a value that is the same in every lane, moved to a scalar register pair
+__device__ __forceinline__ double wave_uniform(double x)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(x);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
 // x^D by repeated squaring (D is a compile-time constant)
@@ -184,17 +193,18 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
             const double eq = fm_exp(-0.5 * q);
             double A, u1;
             philox_uniform2(key, gchain, (uint32_t)i, TAG_RWM_UNIFORM, 0u, A, u1);
-            const double logA = fm_log<true>(A);
+            const double logA = fm_log<false>(A); // A is in the open interval (0,1)
             const double di = (double)i;
-            const double sfac = (di - 1.0) / di;
+            const double inv = fm_rcp(di);
+            const double sfac = (di - 1.0) * inv;
 #pragma unroll
             for (int k = 0; k < D; ++k) Hl[k * 64] = Y[k];
             Hl[D * 64] = eq;
             Hl[(D + 1) * 64] = logA;
             if (lane == 0) {
                 Us[0] = sfac;
-                Us[1] = sfac / di;
-                Us[2] = 1.0 / di;
+                Us[1] = sfac * inv;
+                Us[2] = inv;
             }
             lds_barrier(); // hand-over buffer holds iteration i
             lds_barrier(); // sampler has read it
@@ -207,10 +217,13 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
     const int window = a.acceptance_window;
     const double w = a.acceptance_rate_weight;
     const double *const tp = sh + Lay::TPRM;
-    double theta[D], R[T]; // R: unscaled upper factor, R^T R = covmat (size phase) or covmat_empirical (shape phase)
+    constexpr bool CEN = PackedTarget<KIND, D>::CENTRED;
+    auto shift = [&](int k) -> double { return CEN ? tp[k] : 0.0; }; // stored value = state + shift
+    double theta[D], R[T]; // theta: the chain state (minus the target mean if CENTRED); R: unscaled upper factor,
+                           // R^T R = covmat (size phase) or covmat_empirical (shape phase)
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-        theta[k] = a.d_init ? a.d_init[(int64_t)k * n + cc] : prm[Lay::INIT + k];
+        theta[k] = (a.d_init ? a.d_init[(int64_t)k * n + cc] : prm[Lay::INIT + k]) - shift(k);
         if (MOMENTS) Ml[k * 64] = theta[k];
     }
 #pragma unroll
@@ -224,7 +237,7 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
     double rootTerm, sq_unused;
     fm_sqrt_rsq(a.twopi_pow_d * (prodR * prodR), sq_unused, rootTerm);
     double t_cur = PackedTarget<KIND, D>::eval(theta, tp);
-    double rate = 0.0, scaling_sd = 1.0, scaling_multiplier = 1.0;
+    double rate = 0.0, scaling_sd = 1.0;
     uint64_t win_bits = 0;
     int win_len = 0;
     int32_t status = MCMC_CHAIN_OK, n_shape = 0;
@@ -242,9 +255,9 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
             for (int k = 0; k < D; ++k) Y[k] = Hl[k * 64];
             const double eq = Hl[D * 64];
             const double logA = Hl[(D + 1) * 64];
-            sfac = Us[0];
-            bfac = Us[1];
-            inv_i = Us[2];
+            sfac = wave_uniform(Us[0]);
+            bfac = wave_uniform(Us[1]);
+            inv_i = wave_uniform(Us[2]);
             lds_barrier(); // buffer free again
 
             // ---- proposal theta + Y chol(covmat_proposal) = theta + s (Y R) (:149-154) -----------
@@ -278,7 +291,7 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
             if (i == next_keep) {
                 if (a.d_trace && live) {
 #pragma unroll
-                    for (int k = 0; k < D; ++k) a.d_trace[(t_kept * D + k) * n + c] = theta[k];
+                    for (int k = 0; k < D; ++k) a.d_trace[(t_kept * D + k) * n + c] = theta[k] + shift(k);
                 }
                 next_keep += a.thin;
                 ++t_kept;
@@ -308,7 +321,7 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
             const int in = i + 1;
             const double din = (double)in;
             if (ass != 0 && in >= ass && (ashs == 0 || mul_rn(rate, din) < (double)ashs)) {
-                scaling_multiplier = fm_exp(a.d_cool_pow[in] * (rate - 0.234));
+                const double scaling_multiplier = fm_exp(a.d_cool_pow[in] * (rate - 0.234));
                 scaling_sd = mul_rn(scaling_sd, scaling_multiplier);
                 scaling_sd = (a.max_scaling_sd < scaling_sd) ? a.max_scaling_sd : scaling_sd; // std::min
                 const double s2 = mul_rn(scaling_sd, scaling_sd);
@@ -395,8 +408,8 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
     if (live) {
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-            if (a.d_final_theta) a.d_final_theta[(int64_t)k * n + c] = theta[k];
-            if (MOMENTS && a.d_final_mean) a.d_final_mean[(int64_t)k * n + c] = Ml[k * 64];
+            if (a.d_final_theta) a.d_final_theta[(int64_t)k * n + c] = theta[k] + shift(k);
+            if (MOMENTS && a.d_final_mean) a.d_final_mean[(int64_t)k * n + c] = Ml[k * 64] + shift(k);
         }
         if (MOMENTS && a.d_final_cov) {
 #pragma unroll
