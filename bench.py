@@ -1,11 +1,18 @@
 #!/usr/bin/env python3
-"""Headline benchmark: chain-iterations/sec of the adaptive random-walk Metropolis hot path.
+"""Headline benchmark: chain-iterations/sec of the two sampling hot paths on MI355X.
 
-Workload at N=1 = BASELINE.json configs[1] (C2): adaptive RW Metropolis on a 10-D correlated
+Default workload = BASELINE.json configs[1] (C2): adaptive RW Metropolis on a 10-D correlated
 Gaussian (Sigma_ij = 0.9^|i-j|, given as precision), 65,536 chains x 1e4 iterations, FP64,
 adapt_size_start 100, adapt_shape_start 500, covmat I, per-chain start ~ N(0, 4I) from
 Philox(seed 1), full theta trace written to HBM (52.4 GB).  One "step" = one pass of the hot
 path over that batch = ONE kernel launch advancing every chain by n_iterations.
+
+--workload selects the other single-GPU shapes of BASELINE.json / SURVEY.md section 8d:
+  c3  TMVN Gibbs d=10, box bounds [-1,2], 1,048,576 chains x 2,000 sweeps, full trace (168 GB)
+  c4  adaptive RW Metropolis d=100 (per-GPU share of config 4: 131,072 chains x 5,000 iterations,
+      adapt 200/1000, trace thinned x10)
+  c5  TMVN Gibbs d=128, lower = +4 conditional sd, upper = +Inf (tail path), per-GPU share of
+      config 5: 1,048,576 chains x 200 sweeps, last state + running moments only
 
 For N>1 every rank runs the same per-GPU workload on its own chains (chain_offset = rank *
 n_chains; weak scaling; no data-path collective -- chains are independent).  After the timed
@@ -31,17 +38,23 @@ HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s
 
 
 def rwm_flops_per_iter(d, with_chol):
-    """proposal d(d+1) + target 2d^2+3d + moments 1.5d(d+1)+3d (+ d^3/3 Cholesky)."""
+    """proposal d(d+1) + target 2d^2+3d + moments 1.5d(d+1)+3d; + d^3/3 for the
+    Cholesky factorization in shape-phase iterations (the size phase / rwMCMC have no Cholesky term)."""
     f = 4.5 * d * d + 8.5 * d
     return f + (d ** 3) / 3.0 if with_chol else f
 
 
-def pmc_traffic_bytes(n_chains, n_iter, d):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r1_c2_pmc.csv), for the
-    default C2 shape only: WRITE_SIZE + 2 x FETCH_SIZE (KiB; the x2 is the gfx950 FETCH_SIZE correction of
+def gibbs_flops_per_sweep(d):
+    """d * [2(d-1) dot + 2 C_pnorm + C_qnorm + 9], C_pnorm = 50, C_qnorm = 35."""
+    return d * (2.0 * d + 142.0)
+
+
+def pmc_traffic_bytes(tag):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/<tag>_pmc.csv), default shape
+    only: WRITE_SIZE + 2 x FETCH_SIZE (KiB; the x2 is the gfx950 FETCH_SIZE correction of
     MI355X_MICROARCH.md).  bench.py cannot collect PMC counters itself, so other shapes report null."""
-    path = os.path.join(ROOT, "profiles", "r1_c2_pmc.csv")
-    if (n_chains, n_iter, d) != (65536, 10000, 10) or not os.path.exists(path):
+    path = os.path.join(ROOT, "profiles", f"{tag}_pmc.csv")
+    if not os.path.exists(path):
         return None
     vals = {}
     for line in open(path):
@@ -55,36 +68,48 @@ def pmc_traffic_bytes(n_chains, n_iter, d):
     return (vals["WRITE_SIZE"] + 2.0 * vals["FETCH_SIZE"]) * 1024.0
 
 
-def c2_problem(d=10, rho=0.9):
+def ar1(d, rho):
     idx = np.arange(d)
-    Sig = rho ** np.abs(idx[:, None] - idx[None, :])
-    H = np.linalg.inv(Sig)
-    return Sig, 0.5 * (H + H.T)
+    return rho ** np.abs(idx[:, None] - idx[None, :])
 
 
-def cpu_baseline(d, n_iter, ass, ashs, budget_s=12.0):
-    """The oracle (a port of the reference loop: fresh chol + 2 det + 2 inv per iteration, compiled
-    C target instead of an R closure) on the host cores: one chain per thread, same config."""
+def sym_inv(S):
+    H = np.linalg.inv(S)
+    return 0.5 * (H + H.T)
+
+
+def c4_sigma(d=100):
+    A = np.random.default_rng(4).standard_normal((d, d))
+    return A @ A.T / d + np.eye(d)
+
+
+# --------------------------------------------------------------------------------------------
+# CPU baselines: the oracle (a port of the reference loops) on the host cores, one chain per thread
+def _threads():
+    return max(1, min(16, os.cpu_count() or 1))
+
+
+def cpu_baseline_rwm(d, H, n_iter, ass, ashs, cov0, init_sd, budget_s=12.0):
+    """adaptMCMC as the reference runs it: fresh chol + 2 det + 2 inv per iteration, compiled C target
+    instead of an R closure (which favours the reference)."""
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import oracle as O
 
     O.build()
-    _, H = c2_problem(d)
     tgt = O.gaussian_target(np.zeros(d), H)
-    cores = max(1, min(16, os.cpu_count() or 1))
+    cores = _threads()
     rng = np.random.default_rng(1)
 
     def one(seed):
-        init = 2.0 * rng.standard_normal(d)
-        O.adaptMCMC_seeded(tgt, init, np.eye(d), n_iter, ass, 0.0, 0, ashs, float(seed))
+        init = init_sd * rng.standard_normal(d)
+        O.adaptMCMC_seeded(tgt, init, cov0, n_iter, ass, 0.0, 0, ashs, float(seed))
         return n_iter
 
     t0 = time.perf_counter()
     one(0)
     t_one = time.perf_counter() - t0
-    per_thread = max(1, int(budget_s / max(t_one, 1e-3)))
-    per_thread = min(per_thread, 64)
+    per_thread = min(64, max(1, int(budget_s / max(t_one, 1e-3))))
     n_chains = cores * per_thread
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
@@ -98,14 +123,47 @@ def cpu_baseline(d, n_iter, ass, ashs, budget_s=12.0):
     }
 
 
+def cpu_baseline_gibbs(mu, sigma, lower, upper, init, n_sweeps, budget_s=12.0):
+    """rtmvnorm_gibbs as the reference runs it (d sub-block inverses up front, copy-and-shed per coordinate)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import oracle as O
+
+    O.build()
+    d = len(mu)
+    cores = _threads()
+
+    def one(seed):
+        U = np.random.default_rng(seed).random(n_sweeps * d)
+        O.rtmvnorm_gibbs(n_sweeps, mu, sigma, lower, upper, init, U)
+        return n_sweeps
+
+    t0 = time.perf_counter()
+    one(0)
+    t_one = time.perf_counter() - t0
+    per_thread = min(64, max(1, int(budget_s / max(t_one, 1e-3))))
+    n_chains = cores * per_thread
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        done = sum(ex.map(one, range(1, n_chains + 1)))
+    dt = time.perf_counter() - t0
+    return {
+        "value": done / dt, "unit": "chain-sweeps/s", "cores": cores, "kind": "port",
+        "sample": f"{n_chains} chains x {n_sweeps} sweeps of the same config, one chain per thread "
+                  f"(oracle/mcmc_oracle.c, numpy uniforms generated inside the timed region)",
+        "per_core": done / dt / cores,
+    }
+
+
+# --------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
-    ap.add_argument("--iters", type=int, default=10000)
-    ap.add_argument("--d", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default="c2")
+    ap.add_argument("--chains", type=int, default=None, help="chains per GPU (default: the workload's)")
+    ap.add_argument("--iters", type=int, default=None, help="iterations / sweeps (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true")
     args = ap.parse_args()
@@ -123,17 +181,61 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    d, n_chains, n_iter = args.d, args.chains, args.iters
-    ass, ashs = 100, 500
-    Sig, H = c2_problem(d)
-    target = mcmc_amd.Target.gaussian(np.zeros(d), H)
+    wl = args.workload
+    defaults = {"c2": (65536, 10000, 5, 1), "c3": (1 << 20, 2000, 3, 1), "c4": (131072, 5000, 1, 0), "c5": (1 << 20, 200, 2, 1)}
+    n_chains = args.chains or defaults[wl][0]
+    n_iter = args.iters or defaults[wl][1]
+    steps = args.steps if args.steps is not None else defaults[wl][2]
+    warmup = args.warmup if args.warmup is not None else defaults[wl][3]
     chain_offset = rank * n_chains
-    init = mcmc_amd.init_normal(1, n_chains, np.zeros(d), 2.0, chain_offset=chain_offset)
-    out = {"theta_trace": torch.empty((n_iter, d, n_chains), dtype=torch.float64, device="cuda")}
+    f64 = torch.float64
+    is_rwm = wl in ("c2", "c4")
 
-    def step():
-        return mcmc_amd.adapt_rwm_batch(target, n_chains, init, np.eye(d), n_iter, ass, 0.0, 0, ashs, seed=1,
-                                        chain_offset=chain_offset, out=out)
+    if is_rwm:
+        if wl == "c2":
+            d, ass, ashs, thin, init_sd = 10, 100, 500, 1, 2.0
+            Sig = ar1(d, 0.9)
+            desc = (f"C2: adaptive RW Metropolis, {d}-D correlated Gaussian (rho=0.9, precision form), {n_chains} chains/GPU x "
+                    f"{n_iter} iterations, adapt 100/500, full trace to HBM")
+        else:
+            d, ass, ashs, thin, init_sd = 100, 200, 1000, 10, 1.0
+            Sig = c4_sigma(d)
+            desc = (f"C4 (per-GPU share): adaptive RW Metropolis, {d}-D Gaussian Sigma=AA'/d+I, {n_chains} chains/GPU x {n_iter} "
+                    f"iterations, adapt 200/1000, trace thinned x10")
+        H = sym_inv(Sig)
+        cov0 = np.eye(d)
+        target = mcmc_amd.Target.gaussian(np.zeros(d), H)
+        init = mcmc_amd.init_normal(1, n_chains, np.zeros(d), init_sd, chain_offset=chain_offset)
+        out = {"theta_trace": torch.empty((n_iter // thin, d, n_chains), dtype=f64, device="cuda")}
+
+        def step():
+            return mcmc_amd.adapt_rwm_batch(target, n_chains, init, cov0, n_iter, ass, 0.0, 0, ashs, seed=1, thin=thin,
+                                            chain_offset=chain_offset, out=out)
+        trace_key = "theta_trace"
+    else:
+        if wl == "c3":
+            d, thin, tail_safe, want_trace = 10, 1, False, True
+            sigma = ar1(d, 0.5)
+            lower, upper, init_state = np.full(d, -1.0), np.full(d, 2.0), np.zeros(d)
+            desc = (f"C3: TMVN Gibbs d={d}, Sigma_ij=0.5^|i-j|, box [-1,2], {n_chains} chains/GPU x {n_iter} sweeps, full trace to HBM")
+        else:
+            d, thin, tail_safe, want_trace = 128, 1, True, False
+            sigma = ar1(d, 0.3)
+            _, sd_c = mcmc_amd.tmvn_precompute(sigma)
+            lower, upper = 4.0 * np.asarray(sd_c), np.full(d, np.inf)
+            init_state = lower + 0.1
+            desc = (f"C5 (per-GPU share): TMVN Gibbs d={d}, Sigma_ij=0.3^|i-j|, lower=+4 conditional sd, upper=+Inf (tail path), "
+                    f"{n_chains} chains/GPU x {n_iter} sweeps, last state + running moments")
+        mu = np.zeros(d)
+        out = {}
+        if want_trace:
+            out["trace"] = torch.empty((n_iter // thin, d, n_chains), dtype=f64, device="cuda")
+
+        def step():
+            return mcmc_amd.tmvn_gibbs_batch(n_chains, n_iter, mu, sigma, lower, upper, init_state, seed=2 if wl == "c3" else 5,
+                                             thin=thin, burn=n_iter // 2, chain_offset=chain_offset, tail_safe=tail_safe,
+                                             trace=want_trace, moments=not want_trace, out=out)
+        trace_key = "trace"
 
     def fence():
         torch.cuda.synchronize()
@@ -141,10 +243,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    res = None
+    for _ in range(warmup):
+        res = step()
     fence()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
     for a, b in evs:
         a.record()
@@ -154,51 +257,75 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))  # HIP events on the launch stream
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=f64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # ---- after the timed region: convergence diagnostics (one all-reduce of 3d+1 doubles)
-    burn = min(n_iter // 2, 2000)
-    mean, var = diag.chain_moments(res["theta_trace"], burn)
-    rhat = diag.rhat(mean, var, n_iter - burn)
+    extra = {}
     status_bad = int((res["status"] != 0).sum().item())
-    ess_per_s = None
-    if not args.no_ess:
-        sub = res["theta_trace"][:, :, : min(1024, n_chains)].contiguous()
-        ess = diag.chain_ess(sub, burn, 500)
-        ess_chain = ess.min(dim=0).values.mean().item()  # min over coordinates, mean over the sampled chains
-        ess_per_s = ess_chain * n_chains * world / (elapsed / args.steps)
-    acc_mean = float(res["acceptance_rate"].mean().item())
+    if trace_key in res:
+        n_kept = res[trace_key].shape[0]
+        burn = min(n_kept // 2, 2000)
+        mean, var = diag.chain_moments(res[trace_key], burn)
+        extra["rhat_max"] = float(np.max(diag.rhat(mean, var, n_kept - burn)))
+        if not args.no_ess:
+            sub = res[trace_key][:, :, : min(1024, n_chains)].contiguous()
+            ess = diag.chain_ess(sub, burn, min(500, (n_kept - burn) // 2))
+            ess_chain = ess.min(dim=0).values.mean().item()  # min over coordinates, mean over the sampled chains
+            extra["ess_per_sec"] = ess_chain * n_chains * world / (elapsed / steps)
+    else:
+        n_mom = n_iter - n_iter // 2
+        mean, var = res["mean"], res["m2"] / max(1, n_mom - 1)
+        extra["rhat_max"] = float(np.max(diag.rhat(mean, var, n_mom)))
+    if is_rwm:
+        extra["acceptance_rate_mean"] = float(res["acceptance_rate"].mean().item())
+        shape_iters = float(res["shape_iterations"].to(f64).sum().item())
+        extra["shape_phase_fraction"] = shape_iters / (n_chains * n_iter)
+    extra["chains_failed"] = status_bad
 
     if rank == 0:
-        units = n_chains * n_iter  # chain-iterations per launch per GPU
-        flops_launch = n_chains * (n_iter * rwm_flops_per_iter(d, False) + (n_iter - ass + 1) * (d ** 3) / 3.0)
+        units = n_chains * n_iter  # chain-iterations (chain-sweeps) per launch per GPU
+        if is_rwm:
+            flops_launch = units * rwm_flops_per_iter(d, False) + shape_iters * (d ** 3) / 3.0
+            kept = n_iter // thin
+            kernel = f"rwm_pair_kernel<{d},gaussian>" if d <= 10 else "rwm_block_kernel"
+            per_unit = {"flops_size_phase": rwm_flops_per_iter(d, False), "flops_shape_phase": rwm_flops_per_iter(d, True)}
+            unit = "chain-iterations/s"
+            metric = "chain-iterations/sec (adaptive RW Metropolis, whole job)"
+        else:
+            flops_launch = units * gibbs_flops_per_sweep(d)
+            kept = n_iter // thin if want_trace else 0
+            kernel = "gibbs_kernel"
+            per_unit = {"flops_per_chain_sweep": gibbs_flops_per_sweep(d)}
+            unit = "chain-sweeps/s"
+            metric = "chain-iterations/sec (TMVN Gibbs sweeps, whole job)"
+        bytes_launch = 8.0 * d * n_chains * kept
         achieved_tf = flops_launch / (kern_ms * 1e-3) / 1e12
-        bytes_launch = 8.0 * d * units
         line = {
-            "metric": "chain-iterations/sec (adaptive RW Metropolis, whole job)",
-            "value": units * world * args.steps / elapsed,
-            "unit": "chain-iterations/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "metric": metric,
+            "value": units * world * steps / elapsed,
+            "unit": unit,
+            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"C2: adaptive RW Metropolis, {d}-D correlated Gaussian (rho=0.9, precision form), "
-                                   f"{n_chains} chains/GPU x {n_iter} iterations, adapt 100/500, full trace to HBM",
-                       "chains_per_gpu": n_chains, "iterations": n_iter, "d": d, "parallelism": f"chains sharded x{world}"},
+            "config": {"workload": desc, "chains_per_gpu": n_chains, "iterations": n_iter, "d": d,
+                       "parallelism": f"chains sharded x{world}"},
             "roofline": {"bound": "fp64-valu", "achieved": achieved_tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tf / FP64_VALU_PEAK_TFLOPS, "traffic": pmc_traffic_bytes(n_chains, n_iter, d),
-                         "algorithmic_bytes": bytes_launch,
-                         "kernel": f"rwm_lane_kernel<{d},gaussian>", "kernel_ms": kern_ms,
-                         "flops_per_chain_iteration": rwm_flops_per_iter(d, True),
+                         "frac": achieved_tf / FP64_VALU_PEAK_TFLOPS,
+                         "traffic": pmc_traffic_bytes(f"r1_{wl}") if (n_chains, n_iter) == defaults[wl][:2] else None,
+                         "algorithmic_bytes": bytes_launch, "algorithmic_flops": flops_launch,
+                         "kernel": kernel, "kernel_ms": kern_ms, **per_unit,
                          "hbm_write_GBs": bytes_launch / (kern_ms * 1e-3) / 1e9,
                          "hbm_write_frac": bytes_launch / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "ess_per_sec": ess_per_s, "rhat_max": float(np.max(rhat)), "acceptance_rate_mean": acc_mean,
-            "chains_failed": status_bad,
+            **extra,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(d, n_iter, ass, ashs)
+            if is_rwm:
+                line["cpu_baseline"] = cpu_baseline_rwm(d, H, min(n_iter, 10000 if d <= 10 else 300), ass, ashs, cov0, init_sd)
+            else:
+                line["cpu_baseline"] = cpu_baseline_gibbs(mu, sigma, lower, upper, init_state, min(n_iter, 2000 if d <= 10 else 50))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -18,6 +18,8 @@ constexpr int kMaxLaneDimRwm = 12;
 constexpr int kMaxPairDimRwm = 10;
 // largest d of the LDS-resident kernels (one 64-lane workgroup must fit 160 KiB of LDS)
 constexpr int kMaxDimGibbs = 256;
+// above this d the Gibbs regression rows are staged through LDS by the workgroup (wide variant)
+constexpr int kGibbsLaneMaxDim = 32;
 constexpr int kMaxDimRwm = 128;
 
 int set_error(int code, const char *fmt, ...);

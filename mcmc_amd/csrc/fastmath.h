@@ -43,6 +43,13 @@ __device__ __forceinline__ double sconst(double x)
     return x;
 }
 
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt,
+// i.e. it would hold the sampler until its trace stores to HBM are acknowledged, every iteration.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // a / b for finite, normal, well-scaled operands; error <= ~1.5 ulp.
 __device__ __forceinline__ double fm_rcp(double b)
 {

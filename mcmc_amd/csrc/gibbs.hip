@@ -96,6 +96,156 @@ __global__ __launch_bounds__(64, 3) void gibbs_kernel(const GibbsArgs a, const d
     if (live && a.d_status) a.d_status[c] = status;
 }
 
+// ------------------------------------------------------------------------------------------
+// Wide variant for d > 32.  There the regression rows P no longer fit the 16 KB scalar cache (130 KB at
+// d = 128) and the LDS-resident state (64 KB per 64 chains at d = 128) leaves room for two chain groups
+// per CU: with the kernel above that is two waves on four SIMDs, each exposed to every scalar-load and
+// LDS latency (measured 34 000 cycles per coordinate and wave, 16 times the d = 10 figure).
+//
+// Here a workgroup holds G chain groups and 2 G wavefronts.  Per group a DRAW wave and a DOT wave work
+// one coordinate apart:
+//   * while the draw wave turns coordinate i into a sample (2 x pnorm, qnorm: the long dependent
+//     chain), the dot wave forms for coordinate i+1 the conditional-mean sum over every k except i and
+//     i+1 -- x_i is the only state element that changes meanwhile -- and the uniform u_(i+1), and
+//     leaves both in a double-buffered LDS slot;
+//   * the draw wave then adds the one missing term P[i+1][i] x_i (x_i is still in a register).
+// So the d-term dot product is off the critical path, and all four SIMDs of the CU have a wave.
+// The rows are shared by the workgroup: every thread fetches one or two values of row i+2 (P and the
+// five scalars, coalesced) while step i runs and drops them into a three-slot LDS ring before the
+// single barrier that ends the step; the barrier waits for LDS traffic only, so trace and moment
+// stores stay in flight.  The running moments of the next coordinate are prefetched the same way.
+// The sum is associated differently from the reference's left-to-right loop
+// (tmvrnormGibbs.cpp:124-127): the x_(i-1) term is added last.
+//
+// rows block in HBM: d rows of W doubles: P_i padded to d entries (entry i is 0 and never read), mu_i,
+// sd_i, 1/sd_i, lower_i, upper_i; then init[d].
+constexpr int kWideMaxPrefetch = 3; // ceil(W / threads) at d = 256 (one group, 128 threads)
+
+template <bool TAIL_SAFE, bool MOMENTS>
+__global__ __launch_bounds__(512) void gibbs_wide_kernel(const GibbsArgs a, const double *__restrict__ rows, int W)
+{
+    extern __shared__ double lds[]; // [3][W] row ring, [G][2][2][64] hand-over slots, then per group the centred state [d][64]
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = nthreads >> 7;
+    const bool dotter = wave >= G;
+    const int group = dotter ? wave - G : wave;
+    const int d = a.d;
+    const int64_t c = ((int64_t)blockIdx.x * G + group) * 64 + lane;
+    const int64_t n = a.n_chains;
+    const bool live = c < n;
+    const int64_t cc = live ? c : n - 1; // lanes past the end shadow the last chain and store nothing
+    double *const ring = lds;
+    double *const slot = lds + 3 * W + (size_t)group * 256 + lane;           // [parity][0: sum, 1: u][lane]
+    double *const xc = lds + 3 * W + (size_t)G * 256 + (size_t)group * d * 64 + lane; // element k at xc[k * 64]
+    const double *const init = rows + (size_t)d * W;
+    const int64_t total = (int64_t)a.n_sweeps * d; // steps; step t handles coordinate t % d of sweep t / d + 1
+
+    // state, rows 0 and 1
+    if (!dotter) {
+        for (int k = 0; k < d; ++k) {
+            const double x0 = a.d_init ? a.d_init[(int64_t)k * n + cc] : init[k];
+            xc[k * 64] = x0 - rows[(size_t)k * W + d];
+            if (MOMENTS && live) {
+                a.d_mean[(int64_t)k * n + c] = 0.0;
+                a.d_m2[(int64_t)k * n + c] = 0.0;
+            }
+        }
+    }
+    for (int e = tid; e < 2 * W; e += nthreads) ring[e] = rows[e];
+    __syncthreads();
+
+    // what the dot wave leaves for coordinate i of sweep j in slot parity p
+    auto prepare = [&](int i, int j, const double *row, int p) {
+        const int skip = (i == 0) ? d - 1 : i - 1; // the element the draw wave is still changing
+        const int lo = skip < i ? skip : i, hi = skip < i ? i : skip; // d >= 3: two distinct indices
+        double s = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < lo; ++k) s += row[k] * xc[k * 64];
+#pragma unroll 8
+        for (int k = lo + 1; k < hi; ++k) s += row[k] * xc[k * 64];
+#pragma unroll 8
+        for (int k = hi + 1; k < d; ++k) s += row[k] * xc[k * 64];
+        double u;
+        if (a.d_U) {
+            u = a.d_U[((int64_t)(j - 1) * d + i) * n + cc];
+        } else {
+            double ua, ub;
+            philox_uniform2(PhiloxKey(a.seed), (uint64_t)(a.chain_offset + cc), (uint32_t)j, TAG_GIBBS, (uint32_t)(i >> 1), ua, ub);
+            u = (i & 1) ? ub : ua;
+        }
+        slot[(p * 2 + 0) * 64] = s;
+        slot[(p * 2 + 1) * 64] = u;
+    };
+
+    if (dotter) prepare(0, 1, ring, 0);
+    lds_barrier();
+
+    int32_t status = MCMC_CHAIN_OK;
+    double cm = 0.0, cq = 0.0; // running mean / M2 of the current coordinate (prefetched)
+    double xprev = dotter ? 0.0 : xc[(d - 1) * 64]; // centred x of the previous coordinate
+    int i = 0, j = 1, r0 = 0;  // coordinate, sweep, ring slot of row i
+    for (int64_t t = 0; t < total; ++t) {
+        const int r1 = (r0 == 2) ? 0 : r0 + 1, r2 = (r1 == 2) ? 0 : r1 + 1;
+        const int i1 = (i + 1 == d) ? 0 : i + 1, i2 = (i1 + 1 == d) ? 0 : i1 + 1;
+        const int p = (int)(t & 1);
+        // every thread: fetch row i+2 for the ring
+        double pre[kWideMaxPrefetch];
+#pragma unroll
+        for (int q = 0; q < kWideMaxPrefetch; ++q) {
+            const int e = tid + q * nthreads;
+            pre[q] = (e < W) ? rows[(size_t)i2 * W + e] : 0.0;
+        }
+        if (dotter) {
+            if (t + 1 < total) prepare(i1, i1 == 0 ? j + 1 : j, ring + r1 * W, p ^ 1);
+        } else {
+            const double *const row = ring + r0 * W;
+            double nm = 0.0, nq = 0.0;
+            if (MOMENTS && live) {
+                nm = a.d_mean[(int64_t)i1 * n + c];
+                nq = a.d_m2[(int64_t)i1 * n + c];
+            }
+            const bool keep = a.d_trace && (j % a.thin) == 0;
+            const bool mom = MOMENTS && j > a.burn;
+            // conditional mean mu_i + P_i (x[-i] - mu[-i])   (tmvrnormGibbs.cpp:124-127)
+            const int prev = (i == 0) ? d - 1 : i - 1;
+            const double s = slot[(p * 2 + 0) * 64] + row[prev] * xprev;
+            const double u = slot[(p * 2 + 1) * 64];
+            const double mui = row[d];
+            const double xi = rtnorm_draw_std<TAIL_SAFE>(u, mui + s, row[d + 1], row[d + 2], row[d + 3], row[d + 4]);
+            xprev = xi - mui;
+            xc[i * 64] = xprev;
+            if (!isfinite(xi) && status == MCMC_CHAIN_OK) status = (j << 4) | MCMC_CHAIN_NONFINITE_STATE;
+            if (live) {
+                if (keep) a.d_trace[((int64_t)(j / a.thin - 1) * d + i) * n + c] = xi;
+                if (j == a.n_sweeps && a.d_final) a.d_final[(int64_t)i * n + c] = xi;
+                if (mom) {
+                    const double inv = 1.0 / (double)(j - a.burn);
+                    const double delta = xi - cm;
+                    const double mean = cm + delta * inv;
+                    a.d_mean[(int64_t)i * n + c] = mean;
+                    a.d_m2[(int64_t)i * n + c] = cq + delta * (xi - mean);
+                }
+            }
+            cm = nm;
+            cq = nq;
+        }
+        // row i+2 goes into the free ring slot (it held row i-1, last read one step ago)
+        double *const nxt = ring + r2 * W;
+#pragma unroll
+        for (int q = 0; q < kWideMaxPrefetch; ++q) {
+            const int e = tid + q * nthreads;
+            if (e < W) nxt[e] = pre[q];
+        }
+        lds_barrier(); // x_i, the slot for step t+1 and row i+2 are in LDS; trace / moment stores stay in flight
+        r0 = r1;
+        i = i1;
+        if (i == 0) ++j;
+    }
+    if (!dotter && live && a.d_status) a.d_status[c] = status;
+}
+
 // uniforms a Philox Gibbs run draws, [n_sweeps][d][n_chains]
 __global__ __launch_bounds__(256) void gibbs_streams_kernel(uint64_t seed, int64_t chain_offset, int64_t n,
                                                             int32_t n_sweeps, int32_t d, double *U)
@@ -154,13 +304,52 @@ int launch_gibbs(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipSt
     blob.insert(blob.end(), p.init.begin(), p.init.end());
     for (int k = 0; k < d; ++k) blob.push_back(1.0 / p.sd[k]);
     blob.insert(blob.end(), p.P.begin(), p.P.begin() + (size_t)d * (d - 1));
+    const bool moments = a.d_mean != nullptr;
+    if (d > kGibbsLaneMaxDim) { // wide variant: rows of W doubles, shared by the waves of a workgroup
+        const int W = (d + 5 + 1) & ~1;
+        std::vector<double> rows((size_t)d * W + d, 0.0);
+        for (int i = 0; i < d; ++i) {
+            double *r = rows.data() + (size_t)i * W;
+            for (int k = 0, cidx = 0; k < d; ++k)
+                if (k != i) r[k] = p.P[(size_t)i * (d - 1) + cidx++];
+            r[d] = p.mu[i];
+            r[d + 1] = p.sd[i];
+            r[d + 2] = 1.0 / p.sd[i];
+            r[d + 3] = p.lower[i];
+            r[d + 4] = p.upper[i];
+        }
+        for (int k = 0; k < d; ++k) rows[(size_t)d * W + k] = p.init[k];
+        const size_t state = (size_t)d * 64 * sizeof(double), rowb = (size_t)3 * W * sizeof(double);
+        int nw = (int)((160 * 1024 - rowb - 4 * 2048) / state); // chain groups per workgroup
+        nw = nw < 1 ? 1 : (nw > 4 ? 4 : nw);
+        if ((W + nw * 128 - 1) / (nw * 128) > kWideMaxPrefetch) return set_error(MCMC_E_UNSUPPORTED, "gibbs: d=%d too wide", d);
+        const size_t ldsw = rowb + (size_t)nw * 2048 + nw * state;
+        double *d_rows = nullptr;
+        MCMC_HIP_CHECK(hipMallocAsync((void **)&d_rows, rows.size() * sizeof(double), s));
+        MCMC_HIP_CHECK(hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, s));
+        MCMC_HIP_CHECK(hipStreamSynchronize(s)); // rows is a local: do not let the copy outlive it
+        const int64_t gridw = (a.n_chains + 64 * nw - 1) / (64 * nw);
+        auto gow = [&](auto kern) -> int {
+            MCMC_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
+            hipLaunchKernelGGL(kern, dim3((unsigned)gridw), dim3(128 * nw), ldsw, s, a, (const double *)d_rows, W);
+            MCMC_HIP_CHECK(hipGetLastError());
+            return MCMC_OK;
+        };
+        int rcw;
+        if (tail_safe)
+            rcw = moments ? gow(gibbs_wide_kernel<true, true>) : gow(gibbs_wide_kernel<true, false>);
+        else
+            rcw = moments ? gow(gibbs_wide_kernel<false, true>) : gow(gibbs_wide_kernel<false, false>);
+        hipError_t ew = hipFreeAsync(d_rows, s);
+        if (rcw == MCMC_OK && ew != hipSuccess) rcw = set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(ew));
+        return rcw;
+    }
     double *d_prm = nullptr;
     MCMC_HIP_CHECK(hipMallocAsync((void **)&d_prm, blob.size() * sizeof(double), s));
     MCMC_HIP_CHECK(hipMemcpyAsync(d_prm, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, s));
     MCMC_HIP_CHECK(hipStreamSynchronize(s)); // blob is a local: do not let the copy outlive it
     const size_t lds = (size_t)d * 64 * sizeof(double);
     const int64_t grid = (a.n_chains + 63) / 64;
-    const bool moments = a.d_mean != nullptr;
     auto go = [&](auto kern) -> int {
         MCMC_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, s, a, (const double *)d_prm);

@@ -116,13 +116,6 @@ struct PairLayout {
     static constexpr int LDS_DOUBLES = SH + kPairGroups * GROUP;
 };
 
-// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt,
-// i.e. it would hold the sampler until its trace stores to HBM are acknowledged, every iteration.
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 // a value that is the same in every lane, moved to a scalar register pair
 __device__ __forceinline__ double wave_uniform(double x)
 {
