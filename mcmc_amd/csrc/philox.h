@@ -38,8 +38,14 @@ __host__ __device__ inline u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     for (int r = 0; r < 10; ++r) {
         uint64_t p0 = (uint64_t)M0 * c0;
         uint64_t p1 = (uint64_t)M1 * c2;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // three-input xor in one instruction (v_bitop3_b32, truth table 0x96); halves the bit-op count of a round
+        uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);
+        uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
+#else
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
         uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+#endif
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
         c0 = n0;

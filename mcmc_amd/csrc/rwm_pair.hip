@@ -33,6 +33,9 @@
 #include "common.h"
 #include "philox.h"
 #include "targets.h"
+#ifndef PAIR_EXPERIMENT
+#define PAIR_EXPERIMENT 0
+#endif
 
 namespace mcmc {
 
@@ -99,14 +102,14 @@ struct PackedTarget<MCMC_TARGET_BANANA, 2> {
 
 constexpr int kPairGroups = 4; // chain groups (of 64) per workgroup = sampler waves = generator waves
 
-// parameter block in HBM (doubles): covdiag[D] tprm[NP] | init[D] R0[T] prodR0
+// parameter block in HBM (doubles): min diag(covmat), tprm[NP] | init[D] R0[T] prodR0
 // the first SH doubles are staged in LDS; the rest is read once (or on a rare phase change)
 template <int D, int KIND, bool MOMENTS>
 struct PairLayout {
     static constexpr int T = D * (D + 1) / 2;
     static constexpr int NP = PackedTarget<KIND, D>::NP;
-    static constexpr int COVD = 0, TPRM = D;
-    static constexpr int SH = (D + NP + 1) & ~1;
+    static constexpr int COVD = 0, TPRM = 2;
+    static constexpr int SH = (2 + NP + 1) & ~1;
     static constexpr int INIT = SH, R0 = SH + D, PROD0 = SH + D + T;
     static constexpr int TOTAL = PROD0 + 1;
     static constexpr int CT = MOMENTS ? T : 0;      // covmat_empirical as [e][lane]
@@ -173,8 +176,12 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
         for (int i = 1; i <= n_iter; ++i) {
             // draws of iteration i, while the sampler works on iteration i - 1
             double Y[D];
+#if PAIR_EXPERIMENT == 1
 #pragma unroll
-            for (int b = 0; 2 * b < D; ++b) {
+            for (int b = 0; b < D; ++b) Y[b] = 0.01 * (b + (i & 7)) - 0.05;
+#endif
+#pragma unroll
+            for (int b = 0; PAIR_EXPERIMENT != 1 && 2 * b < D; ++b) {
                 double z0, z1;
                 philox_normal2(key, gchain, (uint32_t)i, TAG_RWM_NORMAL, (uint32_t)b, z0, z1);
                 Y[2 * b] = z0;
@@ -183,10 +190,14 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
             double q = 0.0;
 #pragma unroll
             for (int j = 0; j < D; ++j) q += Y[j] * Y[j];
+#if PAIR_EXPERIMENT == 1
+            const double eq = 0.5 + q, logA = -1.0 - 0.001 * (double)(i & 1023);
+#else
             const double eq = fm_exp(-0.5 * q);
             double A, u1;
             philox_uniform2(key, gchain, (uint32_t)i, TAG_RWM_UNIFORM, 0u, A, u1);
             const double logA = fm_log<false>(A); // A is in the open interval (0,1)
+#endif
             const double di = (double)i;
             const double inv = fm_rcp(di);
             const double sfac = (di - 1.0) * inv;
@@ -210,6 +221,7 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
     const int window = a.acceptance_window;
     const double w = a.acceptance_rate_weight;
     const double *const tp = sh + Lay::TPRM;
+    const double min_var = wave_uniform(sh[Lay::COVD]); // smallest diagonal entry of covmat (host)
     constexpr bool CEN = PackedTarget<KIND, D>::CENTRED;
     auto shift = [&](int k) -> double { return CEN ? tp[k] : 0.0; }; // stored value = state + shift
     double theta[D], R[T]; // theta: the chain state (minus the target mean if CENTRED); R: unscaled upper factor,
@@ -238,12 +250,23 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
     int next_keep = a.thin; // next iteration whose state is stored
     int64_t t_kept = 0;
 
+#if PAIR_EXPERIMENT == 3
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#define TICK(k) { unsigned long long tn = __builtin_amdgcn_s_memtime(); tacc[k] += tn - tlast; tlast = tn; }
+#else
+#define TICK(k)
+#endif
     // i = 0 is the prologue: adaptation (and factorization) for iteration 1 only
     for (int i = 0; i <= n_iter; ++i) {
         double sfac = 0.0, bfac = 0.0, inv_i = 1.0;
+        // pow(adapt_size_cooling, (i+1) - adapt_size_start) for the adaptation at the end of this iteration:
+        // the scalar load is issued here so that its latency is covered by the sampling step
+        const double cool = (ass != 0 && i < n_iter) ? a.d_cool_pow[i + 1] : 0.0;
         if (i > 0) {
             double Y[D];
+            TICK(7)
             lds_barrier(); // hand-over buffer holds iteration i
+            TICK(0)
 #pragma unroll
             for (int k = 0; k < D; ++k) Y[k] = Hl[k * 64];
             const double eq = Hl[D * 64];
@@ -252,7 +275,12 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
             bfac = wave_uniform(Us[1]);
             inv_i = wave_uniform(Us[2]);
             lds_barrier(); // buffer free again
+#if PAIR_EXPERIMENT == 2
+            theta[0] += Y[0] * eq + logA + sfac + bfac + inv_i;
+            continue;
+#endif
 
+            TICK(1)
             // ---- proposal theta + Y chol(covmat_proposal) = theta + s (Y R) (:149-154) -----------
             double prop[D];
 #pragma unroll
@@ -280,11 +308,13 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
                 for (int k = 0; k < D; ++k) theta[k] = prop[k];
                 t_cur = t_prop;
             }
+            TICK(2)
             // ---- trace (:185) -------------------------------------------------------------------
             if (i == next_keep) {
                 if (a.d_trace && live) {
+                    double *const row = a.d_trace + t_kept * D * n; // wave-uniform part of the address
 #pragma unroll
-                    for (int k = 0; k < D; ++k) a.d_trace[(t_kept * D + k) * n + c] = theta[k] + shift(k);
+                    for (int k = 0; k < D; ++k) row[(int64_t)k * n + c] = theta[k] + shift(k);
                 }
                 next_keep += a.thin;
                 ++t_kept;
@@ -308,19 +338,19 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
             }
         }
 
+        TICK(3)
         // ---- adaptation of covmat_proposal for iteration i + 1 (:117-139) -----------------------
         bool rescale = false, refactor = false;
         if (i < n_iter) {
             const int in = i + 1;
             const double din = (double)in;
             if (ass != 0 && in >= ass && (ashs == 0 || mul_rn(rate, din) < (double)ashs)) {
-                const double scaling_multiplier = fm_exp(a.d_cool_pow[in] * (rate - 0.234));
+                const double scaling_multiplier = fm_exp(cool * (rate - 0.234));
                 scaling_sd = mul_rn(scaling_sd, scaling_multiplier);
                 scaling_sd = (a.max_scaling_sd < scaling_sd) ? a.max_scaling_sd : scaling_sd; // std::min
                 const double s2 = mul_rn(scaling_sd, scaling_sd);
-                bool any_small = false;
-#pragma unroll
-                for (int k = 0; k < D; ++k) any_small |= (mul_rn(s2, sh[Lay::COVD + k]) < 2E-16);
+                // "any diagonal entry of the new matrix < 2e-16" (:126): the smallest variance decides (rounding is monotone)
+                const bool any_small = mul_rn(s2, min_var) < 2E-16;
                 rescale = !any_small && !dead; // covmat_proposal = scaling_sd^2 covmat (:129)
             } else if (ashs != 0 && mul_rn(rate, din) >= (double)ashs) {
                 scaling_sd = a.shape_scaling_sd;
@@ -338,38 +368,39 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
             s_eff = scaling_sd;
         }
 
+        TICK(4)
         // ---- update_sigma / mean of iteration i (:210-214, :42-45) fused with R = chol(covmat_empirical)
         //      for iteration i + 1 (:153) ------------------------------------------------------------
         if constexpr (MOMENTS) {
-            double res[D];
+            {
+                double res[D];
 #pragma unroll
-            for (int k = 0; k < D; ++k) {
-                const double mk = Ml[k * 64];
-                res[k] = theta[k] - mk; // i = 0: exactly zero, C stays 0
-                Ml[k * 64] = mk + res[k] * inv_i;
-            }
-            bool ok = true;
-            double prod = 1.0;
-            double rinv[D];
-#pragma unroll
-            for (int cl = 0; cl < D; ++cl) {
-                double col[D];
-                const double bc = bfac * res[cl];
-#pragma unroll
-                for (int r = 0; r <= cl; ++r) {
-                    const double v = fma(Cl[tri(r, cl) * 64], sfac, bc * res[r]);
-                    Cl[tri(r, cl) * 64] = v;
-                    col[r] = v;
+                for (int k = 0; k < D; ++k) {
+                    const double mk = Ml[k * 64];
+                    res[k] = theta[k] - mk; // i = 0: exactly zero, C stays 0
+                    Ml[k * 64] = mk + res[k] * inv_i;
                 }
-                if (refactor) {
+#pragma unroll
+                for (int cl = 0; cl < D; ++cl) {
+                    const double bc = bfac * res[cl];
+#pragma unroll
+                    for (int r = 0; r <= cl; ++r) Cl[tri(r, cl) * 64] = fma(Cl[tri(r, cl) * 64], sfac, bc * res[r]);
+                }
+            }
+            if (refactor) { // column by column, reading covmat_empirical back from LDS (keeps the register peak low)
+                bool ok = true;
+                double prod = 1.0;
+                double rinv[D];
+#pragma unroll
+                for (int cl = 0; cl < D; ++cl) {
 #pragma unroll
                     for (int r = 0; r < cl; ++r) {
-                        double s = col[r];
+                        double s = Cl[tri(r, cl) * 64];
 #pragma unroll
                         for (int m = 0; m < r; ++m) s -= R[tri(m, r)] * R[tri(m, cl)];
                         R[tri(r, cl)] = s * rinv[r];
                     }
-                    double ajj = col[cl];
+                    double ajj = Cl[tri(cl, cl) * 64];
 #pragma unroll
                     for (int m = 0; m < cl; ++m) ajj -= R[tri(m, cl)] * R[tri(m, cl)];
                     ok = ok && (ajj > 0.0);
@@ -378,8 +409,6 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
                     R[tri(cl, cl)] = rjj;
                     prod *= rjj;
                 }
-            }
-            if (refactor) {
                 prodR = prod;
                 base_emp = true;
                 s_eff = scaling_sd;
@@ -391,6 +420,7 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
                 }
             }
         }
+        TICK(5)
         if (rescale || refactor) { // 1 / sqrt((2 pi)^d det(covmat_proposal)) (:56)
             const double dt = powi<D>(s_eff) * prodR;
             double sq;
@@ -398,6 +428,12 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
         }
     }
 
+#if PAIR_EXPERIMENT == 3
+    if (blockIdx.x == 0 && tid == 0)
+        printf("memtime ticks per iter: wait %.1f read %.1f prop+target+accept %.1f trace+rate %.1f adapt %.1f moments %.1f root %.1f\n",
+               (double)tacc[0] / n_iter, (double)tacc[1] / n_iter, (double)tacc[2] / n_iter, (double)tacc[3] / n_iter,
+               (double)tacc[4] / n_iter, (double)tacc[5] / n_iter, (double)tacc[7] / n_iter);
+#endif
     if (live) {
 #pragma unroll
         for (int k = 0; k < D; ++k) {
@@ -428,11 +464,13 @@ static int launch_rwm_pair_dk(const RwmArgs &a, const RwmParams &p, hipStream_t 
                          target_param_count(KIND, D), (int)p.tparams.size());
     std::vector<double> blob(Lay::TOTAL, 0.0);
     double prod0 = 1.0;
+    double min_var = p.cov_packed[0];
     for (int k = 0; k < D; ++k) {
-        blob[Lay::COVD + k] = p.cov_packed[tri(k, k)];
+        min_var = std::fmin(min_var, p.cov_packed[tri(k, k)]);
         blob[Lay::INIT + k] = p.init[k];
         prod0 *= p.R0_packed[tri(k, k)];
     }
+    blob[Lay::COVD] = min_var;
     PackedTarget<KIND, D>::pack(p.tparams, blob.data() + Lay::TPRM);
     for (int e = 0; e < Lay::T; ++e) blob[Lay::R0 + e] = p.R0_packed[e];
     blob[Lay::PROD0] = prod0;
