@@ -49,6 +49,7 @@ extern "C" {
 #define MCMC_CHAIN_OK 0
 #define MCMC_CHAIN_CHOL_FAILED 1      /* arma::chol would have thrown (adaptMCMC_source.cpp:153) */
 #define MCMC_CHAIN_NONFINITE_STATE 2  /* Gibbs draw became +-Inf/NaN (tmvrnormGibbs.cpp:132 has no tail handling) */
+#define MCMC_CHAIN_SYNC_LOST 3        /* internal hand-shake between the wavefronts of a chain group timed out (a bug, never data) */
 #define MCMC_STATUS_CODE(s) ((s) & 15)
 #define MCMC_STATUS_ITER(s) ((s) >> 4)
 

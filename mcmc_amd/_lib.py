@@ -20,6 +20,7 @@ MCMC_E_CHAIN_FAILED = -5
 MCMC_CHAIN_OK = 0
 MCMC_CHAIN_CHOL_FAILED = 1
 MCMC_CHAIN_NONFINITE_STATE = 2
+MCMC_CHAIN_SYNC_LOST = 3
 
 MCMC_RNG_PHILOX = 0
 MCMC_RNG_INJECTED = 1

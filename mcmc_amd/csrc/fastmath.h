@@ -42,6 +42,13 @@ __device__ __forceinline__ double sconst(double x)
     asm volatile("" : "+s"(x));
     return x;
 }
+// the same, but not before `after` has been computed: keeps the scalar pairs of a polynomial from all being
+// live at once (the scheduler otherwise gathers them at the top of the block and scalar registers spill)
+__device__ __forceinline__ double sconst(double x, double after)
+{
+    asm volatile("" : "+s"(x) : "v"(after));
+    return x;
+}
 
 // Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt,
 // i.e. it would hold the sampler until its trace stores to HBM are acknowledged, every iteration.
@@ -92,22 +99,24 @@ __device__ __forceinline__ double fm_log(double x)
 {
     int e;
     double m = frexp(x, &e); // m in [0.5, 1); v_frexp_* normalise subnormals themselves
-    const bool lo = m < sconst(0.70710678118654752440);
+    const bool lo = m < sconst(0.70710678118654752440, m);
     m = lo ? m + m : m;
     e = lo ? e - 1 : e;
     const double f = m - 1.0;
     const double s = f * fm_rcp(2.0 + f);
     const double z = s * s;
     const double w = z * z;
-    const double t1 = w * (sconst(3.999999999940941908e-01) +
-                           w * (sconst(2.222219843214978396e-01) + w * sconst(1.531383769920937332e-01)));
-    const double t2 = z * (sconst(6.666666666666735130e-01) +
-                           w * (sconst(2.857142874366239149e-01) +
-                                w * (sconst(1.818357216161805012e-01) + w * sconst(1.479819860511658591e-01))));
+    double t1 = fma(w, sconst(1.531383769920937332e-01, w), sconst(2.222219843214978396e-01, w));
+    t1 = fma(w, t1, sconst(3.999999999940941908e-01, t1));
+    t1 *= w;
+    double t2 = fma(w, sconst(1.479819860511658591e-01, w), sconst(1.818357216161805012e-01, w));
+    t2 = fma(w, t2, sconst(2.857142874366239149e-01, t2));
+    t2 = fma(w, t2, sconst(6.666666666666735130e-01, t2));
+    t2 *= z;
     const double R = t2 + t1;
     const double hfsq = 0.5 * f * f;
     const double dk = (double)e;
-    double res = dk * sconst(6.93147180369123816490e-01) - ((hfsq - (s * (hfsq + R) + dk * sconst(1.90821492927058770002e-10))) - f);
+    double res = dk * sconst(6.93147180369123816490e-01, dk) - ((hfsq - (s * (hfsq + R) + dk * sconst(1.90821492927058770002e-10, R))) - f);
     if (FULL) {
         if (x == 0.0) res = -__builtin_inf();
         if (x < 0.0 || x != x) res = __builtin_nan("");
@@ -121,20 +130,20 @@ __device__ __forceinline__ double fm_log(double x)
 __device__ __forceinline__ double fm_exp(double x)
 {
     const double xc = fmin(fmax(x, -1100.0), 1100.0); // keeps k inside int range; the result is 0 / Inf there anyway
-    const double kd = rint(xc * sconst(1.4426950408889634074));
-    double r = fma(kd, -sconst(6.93147180369123816490e-01), xc);
-    r = fma(kd, -sconst(1.90821492927058770002e-10), r);
-    double p = sconst(1.6059043836821613e-10);          // 1/13!
-    p = fma(p, r, sconst(2.08767569878681e-09));          // 1/12!
-    p = fma(p, r, sconst(2.505210838544172e-08));         // 1/11!
-    p = fma(p, r, sconst(2.755731922398589e-07));         // 1/10!
-    p = fma(p, r, sconst(2.7557319223985893e-06));        // 1/9!
-    p = fma(p, r, sconst(2.48015873015873e-05));          // 1/8!
-    p = fma(p, r, sconst(0.0001984126984126984));         // 1/7!
-    p = fma(p, r, sconst(0.001388888888888889));          // 1/6!
-    p = fma(p, r, sconst(0.008333333333333333));          // 1/5!
-    p = fma(p, r, sconst(0.041666666666666664));          // 1/4!
-    p = fma(p, r, sconst(0.16666666666666666));           // 1/3!
+    const double kd = rint(xc * sconst(1.4426950408889634074, xc));
+    double r = fma(kd, -sconst(6.93147180369123816490e-01, kd), xc);
+    r = fma(kd, -sconst(1.90821492927058770002e-10, r), r);
+    double p = sconst(1.6059043836821613e-10, r);          // 1/13!
+    p = fma(p, r, sconst(2.08767569878681e-09, p));          // 1/12!
+    p = fma(p, r, sconst(2.505210838544172e-08, p));         // 1/11!
+    p = fma(p, r, sconst(2.755731922398589e-07, p));         // 1/10!
+    p = fma(p, r, sconst(2.7557319223985893e-06, p));        // 1/9!
+    p = fma(p, r, sconst(2.48015873015873e-05, p));          // 1/8!
+    p = fma(p, r, sconst(0.0001984126984126984, p));         // 1/7!
+    p = fma(p, r, sconst(0.001388888888888889, p));          // 1/6!
+    p = fma(p, r, sconst(0.008333333333333333, p));          // 1/5!
+    p = fma(p, r, sconst(0.041666666666666664, p));          // 1/4!
+    p = fma(p, r, sconst(0.16666666666666666, p));           // 1/3!
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);

@@ -33,9 +33,6 @@
 #include "common.h"
 #include "philox.h"
 #include "targets.h"
-#ifndef PAIR_EXPERIMENT
-#define PAIR_EXPERIMENT 0
-#endif
 
 namespace mcmc {
 
@@ -112,10 +109,11 @@ struct PairLayout {
     static constexpr int SH = (2 + NP + 1) & ~1;
     static constexpr int INIT = SH, R0 = SH + D, PROD0 = SH + D + T;
     static constexpr int TOTAL = PROD0 + 1;
-    static constexpr int CT = MOMENTS ? T : 0;      // covmat_empirical as [e][lane]
-    static constexpr int MT = MOMENTS ? D : 0;      // theta_mean as [k][lane]
-    static constexpr int HAND = D + 2;              // Y[D], exp(-q/2), log A as [e][lane]
-    static constexpr int GROUP = (CT + MT + HAND) * 64 + 8; // + wave-uniform scalars of the iteration
+    // per chain group, all as [element][lane]:
+    static constexpr int DRAW = D + 2;              // generator -> sampler: Y[D], exp(-q/2), log A
+    static constexpr int BACK = MOMENTS ? D : 0;    // sampler -> generator: theta of the iteration just finished
+    static constexpr int CX = MOMENTS ? T : 0;      // covmat_empirical: updated by the generator, read by the sampler when it factors
+    static constexpr int GROUP = (DRAW + BACK + CX) * 64 + 8; // + 8 doubles of flags
     static constexpr int LDS_DOUBLES = SH + kPairGroups * GROUP;
 };
 
@@ -141,6 +139,43 @@ __device__ __forceinline__ double powi(double x)
     }
 }
 
+// ---- hand-shake between the two wavefronts of a chain group: monotone counters in LDS -----------
+// Data is written with ordinary LDS stores, then the counter; LDS operations of one wave complete in
+// order, so a reader that sees the counter sees the data.  The compiler fences keep it from moving LDS
+// accesses across the counter operations.  Every wait is bounded: if a partner never arrives (a bug, not
+// a data-dependent event) the wave gives up, raises the group's abort flag and the chain status says so.
+constexpr int kSpinLimit = 1 << 22;
+enum PairFlag { F_DRAW = 0, F_READ = 1, F_THETA = 2, F_BACKREAD = 3, F_C = 4, F_ABORT = 5 };
+
+__device__ __forceinline__ void flag_set(int *flags, int which, int value)
+{
+    asm volatile("" ::: "memory");
+    __hip_atomic_store(flags + which, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+}
+// the counter as a wave-uniform (scalar) value, so that the polling loop is a scalar branch
+__device__ __forceinline__ int flag_peek(int *flags, int which)
+{
+    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(flags + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+__device__ __forceinline__ bool flag_wait(int *flags, int which, int value)
+{
+    asm volatile("" ::: "memory");
+    bool ok = true;
+    int spin = 0;
+#pragma nounroll
+    while (flag_peek(flags, which) < value) {
+        if (++spin > kSpinLimit || flag_peek(flags, F_ABORT) != 0) {
+            ok = false;
+            flag_set(flags, F_ABORT, 1);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+    return ok;
+}
+
 template <int D, int KIND, bool MOMENTS>
 __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmArgs a, const double *__restrict__ prm)
 {
@@ -160,82 +195,117 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
     const int n_iter = a.n_iterations;
 
     for (int e = tid; e < Lay::SH; e += 128 * kPairGroups) lds[e] = prm[e];
+    double *const G0 = lds + Lay::SH + group * Lay::GROUP;
+    double *const Dl = G0 + lane;                                // draws: slot e at Dl[e * 64]
+    double *const Bl = G0 + Lay::DRAW * 64 + lane;               // theta handed back: Bl[k * 64]
+    double *const Xl = G0 + (Lay::DRAW + Lay::BACK) * 64 + lane; // covmat_empirical on request: Xl[e * 64]
+    int *const flags = (int *)(G0 + (Lay::DRAW + Lay::BACK + Lay::CX) * 64);
+    if (lane < 16 && !generator) flags[lane] = 0;
     __syncthreads();
     const double *const sh = lds;
-    double *const G0 = lds + Lay::SH + group * Lay::GROUP;
-    double *const Cl = G0 + lane;                            // covmat_empirical element e at Cl[e * 64]
-    double *const Ml = G0 + Lay::CT * 64 + lane;             // theta_mean element k at Ml[k * 64]
-    double *const Hl = G0 + (Lay::CT + Lay::MT) * 64 + lane; // hand-over slot e at Hl[e * 64]
-    double *const Us = G0 + (Lay::CT + Lay::MT + Lay::HAND) * 64; // (i-1)/i, (i-1)/i^2, 1/i of the iteration handed over
+    const double *const tp = sh + Lay::TPRM;
+    constexpr bool CEN = PackedTarget<KIND, D>::CENTRED;
+    auto shift = [&](int k) -> double { return CEN ? tp[k] : 0.0; }; // stored value = state + shift
 
-    // Both roles pass the same two barriers per iteration i = 1..n: "hand-over buffer holds iteration i"
-    // and "buffer read, free again"; each role runs its own loop so that neither's registers are live in
-    // the other's code.
+    // ================================ generator ====================================================
+    // Iteration i: the d normals, exp(-|Y|^2/2) and log A of iteration i (while the sampler works on
+    // iteration i-1), then update_sigma / theta_mean for iteration i-1 from the theta the sampler handed
+    // back.  covmat_empirical and theta_mean live in THIS wave's registers; the sampler gets a copy through
+    // LDS only in iterations in which one of its lanes factors it (shape phase).
     if (generator) {
         const PhiloxKey key(a.seed);
-        for (int i = 1; i <= n_iter; ++i) {
-            // draws of iteration i, while the sampler works on iteration i - 1
-            double Y[D];
-#if PAIR_EXPERIMENT == 1
+        double mean[MOMENTS ? D : 1];
+        if (MOMENTS) {
 #pragma unroll
-            for (int b = 0; b < D; ++b) Y[b] = 0.01 * (b + (i & 7)) - 0.05;
-#endif
+            for (int e = 0; e < T; ++e) Xl[e * 64] = 0.0;
 #pragma unroll
-            for (int b = 0; PAIR_EXPERIMENT != 1 && 2 * b < D; ++b) {
-                double z0, z1;
-                philox_normal2(key, gchain, (uint32_t)i, TAG_RWM_NORMAL, (uint32_t)b, z0, z1);
-                Y[2 * b] = z0;
-                if (2 * b + 1 < D) Y[2 * b + 1] = z1;
+            for (int k = 0; k < D; ++k) mean[k] = (a.d_init ? a.d_init[(int64_t)k * n + cc] : prm[Lay::INIT + k]) - shift(k);
+        }
+        bool ok = true;
+        for (int i = 1; i <= n_iter + 1 && ok; ++i) {
+            double Y[D], eq = 0.0, logA = 0.0;
+            if (i <= n_iter) {
+#pragma unroll
+                for (int b = 0; 2 * b < D; ++b) {
+                    double z0, z1;
+                    philox_normal2(key, gchain, (uint32_t)i, TAG_RWM_NORMAL, (uint32_t)b, z0, z1);
+                    Y[2 * b] = z0;
+                    if (2 * b + 1 < D) Y[2 * b + 1] = z1;
+                }
+                double q = 0.0;
+#pragma unroll
+                for (int j = 0; j < D; ++j) q += Y[j] * Y[j];
+                eq = fm_exp(-0.5 * q);
+                double A, u1;
+                philox_uniform2(key, gchain, (uint32_t)i, TAG_RWM_UNIFORM, 0u, A, u1);
+                logA = fm_log<false>(A); // A is in the open interval (0,1)
             }
-            double q = 0.0;
+            if (i <= n_iter) {
+                if (i > 1) ok = flag_wait(flags, F_READ, i - 1); // the draw buffer is free again
 #pragma unroll
-            for (int j = 0; j < D; ++j) q += Y[j] * Y[j];
-#if PAIR_EXPERIMENT == 1
-            const double eq = 0.5 + q, logA = -1.0 - 0.001 * (double)(i & 1023);
-#else
-            const double eq = fm_exp(-0.5 * q);
-            double A, u1;
-            philox_uniform2(key, gchain, (uint32_t)i, TAG_RWM_UNIFORM, 0u, A, u1);
-            const double logA = fm_log<false>(A); // A is in the open interval (0,1)
-#endif
-            const double di = (double)i;
-            const double inv = fm_rcp(di);
-            const double sfac = (di - 1.0) * inv;
-#pragma unroll
-            for (int k = 0; k < D; ++k) Hl[k * 64] = Y[k];
-            Hl[D * 64] = eq;
-            Hl[(D + 1) * 64] = logA;
-            if (lane == 0) {
-                Us[0] = sfac;
-                Us[1] = sfac * inv;
-                Us[2] = inv;
+                for (int k = 0; k < D; ++k) Dl[k * 64] = Y[k];
+                Dl[D * 64] = eq;
+                Dl[(D + 1) * 64] = logA;
+                flag_set(flags, F_DRAW, i);
             }
-            lds_barrier(); // hand-over buffer holds iteration i
-            lds_barrier(); // sampler has read it
+            // theta of iteration i-1, as soon as the sampler has it
+            double th[MOMENTS ? D : 1];
+            if (MOMENTS && i > 1) {
+                ok = ok && flag_wait(flags, F_THETA, i - 1);
+#pragma unroll
+                for (int k = 0; k < D; ++k) th[k] = Bl[k * 64];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // theta is in registers
+                flag_set(flags, F_BACKREAD, i - 1);
+            }
+            if (MOMENTS && i > 1) {
+                // update_sigma (:42-45) and the mean update (:212) of iteration i-1:
+                // C (i-2)/(i-1) + ((i-2)/(i-1)^2 r_a) r_b, one FMA per element
+                const double dm = (double)(i - 1);
+                const double inv = fm_rcp(dm);
+                const double sfac = (dm - 1.0) * inv, bfac = sfac * inv;
+                double res[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    res[k] = th[k] - mean[k];
+                    mean[k] = mean[k] + res[k] * inv;
+                }
+#pragma unroll
+                for (int cl = 0; cl < D; ++cl) {
+                    const double bc = bfac * res[cl];
+#pragma unroll
+                    for (int r = 0; r <= cl; ++r) Xl[tri(r, cl) * 64] = fma(Xl[tri(r, cl) * 64], sfac, bc * res[r]);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                flag_set(flags, F_C, i - 1); // covmat_empirical of iteration i-1 is complete
+            }
+        }
+        if (MOMENTS && live) {
+#pragma unroll
+            for (int k = 0; k < D; ++k)
+                if (a.d_final_mean) a.d_final_mean[(int64_t)k * n + c] = mean[k] + shift(k);
+            if (a.d_final_cov) {
+#pragma unroll
+                for (int cl = 0; cl < D; ++cl) {
+#pragma unroll
+                    for (int r = 0; r < D; ++r)
+                        a.d_final_cov[(int64_t)(cl * D + r) * n + c] = Xl[(r <= cl ? tri(r, cl) : tri(cl, r)) * 64];
+                }
+            }
         }
         return;
     }
 
-    // ---- sampler -----------------------------------------------------------------------------------
+    // ================================ sampler ======================================================
     const int ass = a.adapt_size_start, ashs = a.adapt_shape_start;
     const int window = a.acceptance_window;
     const double w = a.acceptance_rate_weight;
-    const double *const tp = sh + Lay::TPRM;
     const double min_var = wave_uniform(sh[Lay::COVD]); // smallest diagonal entry of covmat (host)
-    constexpr bool CEN = PackedTarget<KIND, D>::CENTRED;
-    auto shift = [&](int k) -> double { return CEN ? tp[k] : 0.0; }; // stored value = state + shift
     double theta[D], R[T]; // theta: the chain state (minus the target mean if CENTRED); R: unscaled upper factor,
                            // R^T R = covmat (size phase) or covmat_empirical (shape phase)
 #pragma unroll
-    for (int k = 0; k < D; ++k) {
-        theta[k] = (a.d_init ? a.d_init[(int64_t)k * n + cc] : prm[Lay::INIT + k]) - shift(k);
-        if (MOMENTS) Ml[k * 64] = theta[k];
-    }
+    for (int k = 0; k < D; ++k) theta[k] = (a.d_init ? a.d_init[(int64_t)k * n + cc] : prm[Lay::INIT + k]) - shift(k);
 #pragma unroll
-    for (int e = 0; e < T; ++e) {
-        if (MOMENTS) Cl[e * 64] = 0.0;
-        R[e] = prm[Lay::R0 + e];
-    }
+    for (int e = 0; e < T; ++e) R[e] = prm[Lay::R0 + e];
     double prodR = prm[Lay::PROD0]; // product of diag(R)
     bool base_emp = false;          // R holds chol(covmat_empirical)
     double s_eff = 1.0;             // scale of covmat_proposal = s_eff^2 R^T R
@@ -246,41 +316,25 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
     uint64_t win_bits = 0;
     int win_len = 0;
     int32_t status = MCMC_CHAIN_OK, n_shape = 0;
-    bool dead = false;
+    bool dead = false, sync_ok = true;
     int next_keep = a.thin; // next iteration whose state is stored
     int64_t t_kept = 0;
 
-#if PAIR_EXPERIMENT == 3
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-#define TICK(k) { unsigned long long tn = __builtin_amdgcn_s_memtime(); tacc[k] += tn - tlast; tlast = tn; }
-#else
-#define TICK(k)
-#endif
-    // i = 0 is the prologue: adaptation (and factorization) for iteration 1 only
-    for (int i = 0; i <= n_iter; ++i) {
-        double sfac = 0.0, bfac = 0.0, inv_i = 1.0;
+    // i = 0 is the prologue: the adaptation for iteration 1 only
+    for (int i = 0; i <= n_iter && sync_ok; ++i) {
         // pow(adapt_size_cooling, (i+1) - adapt_size_start) for the adaptation at the end of this iteration:
         // the scalar load is issued here so that its latency is covered by the sampling step
         const double cool = (ass != 0 && i < n_iter) ? a.d_cool_pow[i + 1] : 0.0;
         if (i > 0) {
             double Y[D];
-            TICK(7)
-            lds_barrier(); // hand-over buffer holds iteration i
-            TICK(0)
+            sync_ok = flag_wait(flags, F_DRAW, i);
 #pragma unroll
-            for (int k = 0; k < D; ++k) Y[k] = Hl[k * 64];
-            const double eq = Hl[D * 64];
-            const double logA = Hl[(D + 1) * 64];
-            sfac = wave_uniform(Us[0]);
-            bfac = wave_uniform(Us[1]);
-            inv_i = wave_uniform(Us[2]);
-            lds_barrier(); // buffer free again
-#if PAIR_EXPERIMENT == 2
-            theta[0] += Y[0] * eq + logA + sfac + bfac + inv_i;
-            continue;
-#endif
+            for (int k = 0; k < D; ++k) Y[k] = Dl[k * 64];
+            const double eq = Dl[D * 64];
+            const double logA = Dl[(D + 1) * 64];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the draws are in registers
+            flag_set(flags, F_READ, i);
 
-            TICK(1)
             // ---- proposal theta + Y chol(covmat_proposal) = theta + s (Y R) (:149-154) -----------
             double prop[D];
 #pragma unroll
@@ -308,7 +362,6 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
                 for (int k = 0; k < D; ++k) theta[k] = prop[k];
                 t_cur = t_prop;
             }
-            TICK(2)
             // ---- trace (:185) -------------------------------------------------------------------
             if (i == next_keep) {
                 if (a.d_trace && live) {
@@ -338,7 +391,6 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
             }
         }
 
-        TICK(3)
         // ---- adaptation of covmat_proposal for iteration i + 1 (:117-139) -----------------------
         bool rescale = false, refactor = false;
         if (i < n_iter) {
@@ -354,9 +406,17 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
                 rescale = !any_small && !dead; // covmat_proposal = scaling_sd^2 covmat (:129)
             } else if (ashs != 0 && mul_rn(rate, din) >= (double)ashs) {
                 scaling_sd = a.shape_scaling_sd;
-                refactor = !dead; // covmat_proposal = scaling_sd^2 covmat_empirical (:138)
+                refactor = MOMENTS && i > 0 && !dead; // covmat_proposal = scaling_sd^2 covmat_empirical (:138)
                 ++n_shape;
             }
+        }
+        // ---- hand theta of iteration i to the generator (update_sigma / mean, :210-214) -------------
+        const bool want_c = MOMENTS && __builtin_amdgcn_ballot_w64(refactor) != 0;
+        if (MOMENTS && i > 0) {
+            if (i > 1) sync_ok = sync_ok && flag_wait(flags, F_BACKREAD, i - 1); // the generator has taken theta of iteration i-1
+#pragma unroll
+            for (int k = 0; k < D; ++k) Bl[k * 64] = theta[k];
+            flag_set(flags, F_THETA, i);
         }
         if (rescale) {
             if (base_emp) { // back from the shape phase: the factor of covmat again
@@ -367,60 +427,45 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
             }
             s_eff = scaling_sd;
         }
-
-        TICK(4)
-        // ---- update_sigma / mean of iteration i (:210-214, :42-45) fused with R = chol(covmat_empirical)
-        //      for iteration i + 1 (:153) ------------------------------------------------------------
+        // ---- R = chol(covmat_empirical) for iteration i + 1 (:153) ------------------------------
         if constexpr (MOMENTS) {
-            {
-                double res[D];
+            if (want_c) {
+                sync_ok = sync_ok && flag_wait(flags, F_C, i);
+                if (refactor) {
+                    bool ok = true;
+                    double prod = 1.0;
+                    double rinv[D];
 #pragma unroll
-                for (int k = 0; k < D; ++k) {
-                    const double mk = Ml[k * 64];
-                    res[k] = theta[k] - mk; // i = 0: exactly zero, C stays 0
-                    Ml[k * 64] = mk + res[k] * inv_i;
-                }
+                    for (int cl = 0; cl < D; ++cl) {
 #pragma unroll
-                for (int cl = 0; cl < D; ++cl) {
-                    const double bc = bfac * res[cl];
+                        for (int r = 0; r < cl; ++r) {
+                            double s = Xl[tri(r, cl) * 64];
 #pragma unroll
-                    for (int r = 0; r <= cl; ++r) Cl[tri(r, cl) * 64] = fma(Cl[tri(r, cl) * 64], sfac, bc * res[r]);
-                }
-            }
-            if (refactor) { // column by column, reading covmat_empirical back from LDS (keeps the register peak low)
-                bool ok = true;
-                double prod = 1.0;
-                double rinv[D];
+                            for (int m = 0; m < r; ++m) s -= R[tri(m, r)] * R[tri(m, cl)];
+                            R[tri(r, cl)] = s * rinv[r];
+                        }
+                        double ajj = Xl[tri(cl, cl) * 64];
 #pragma unroll
-                for (int cl = 0; cl < D; ++cl) {
-#pragma unroll
-                    for (int r = 0; r < cl; ++r) {
-                        double s = Cl[tri(r, cl) * 64];
-#pragma unroll
-                        for (int m = 0; m < r; ++m) s -= R[tri(m, r)] * R[tri(m, cl)];
-                        R[tri(r, cl)] = s * rinv[r];
+                        for (int m = 0; m < cl; ++m) ajj -= R[tri(m, cl)] * R[tri(m, cl)];
+                        ok = ok && (ajj > 0.0);
+                        double rjj;
+                        fm_sqrt_rsq(ajj, rjj, rinv[cl]);
+                        R[tri(cl, cl)] = rjj;
+                        prod *= rjj;
                     }
-                    double ajj = Cl[tri(cl, cl) * 64];
+                    prodR = prod;
+                    base_emp = true;
+                    s_eff = scaling_sd;
+                    if (!ok) { // arma::chol throws here; the chain stops and reports where
+                        dead = true;
+                        status = ((i + 1) << 4) | MCMC_CHAIN_CHOL_FAILED;
 #pragma unroll
-                    for (int m = 0; m < cl; ++m) ajj -= R[tri(m, cl)] * R[tri(m, cl)];
-                    ok = ok && (ajj > 0.0);
-                    double rjj;
-                    fm_sqrt_rsq(ajj, rjj, rinv[cl]);
-                    R[tri(cl, cl)] = rjj;
-                    prod *= rjj;
+                        for (int k = 0; k < D; ++k) theta[k] = __builtin_nan("");
+                    }
                 }
-                prodR = prod;
-                base_emp = true;
-                s_eff = scaling_sd;
-                if (!ok) { // arma::chol throws here; the chain stops and reports where
-                    dead = true;
-                    status = ((i + 1) << 4) | MCMC_CHAIN_CHOL_FAILED;
-#pragma unroll
-                    for (int k = 0; k < D; ++k) theta[k] = __builtin_nan("");
-                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // done with the copy before the next hand-back
             }
         }
-        TICK(5)
         if (rescale || refactor) { // 1 / sqrt((2 pi)^d det(covmat_proposal)) (:56)
             const double dt = powi<D>(s_eff) * prodR;
             double sq;
@@ -428,28 +473,12 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
         }
     }
 
-#if PAIR_EXPERIMENT == 3
-    if (blockIdx.x == 0 && tid == 0)
-        printf("memtime ticks per iter: wait %.1f read %.1f prop+target+accept %.1f trace+rate %.1f adapt %.1f moments %.1f root %.1f\n",
-               (double)tacc[0] / n_iter, (double)tacc[1] / n_iter, (double)tacc[2] / n_iter, (double)tacc[3] / n_iter,
-               (double)tacc[4] / n_iter, (double)tacc[5] / n_iter, (double)tacc[7] / n_iter);
-#endif
     if (live) {
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
+        for (int k = 0; k < D; ++k)
             if (a.d_final_theta) a.d_final_theta[(int64_t)k * n + c] = theta[k] + shift(k);
-            if (MOMENTS && a.d_final_mean) a.d_final_mean[(int64_t)k * n + c] = Ml[k * 64] + shift(k);
-        }
-        if (MOMENTS && a.d_final_cov) {
-#pragma unroll
-            for (int cl = 0; cl < D; ++cl) {
-#pragma unroll
-                for (int r = 0; r < D; ++r)
-                    a.d_final_cov[(int64_t)(cl * D + r) * n + c] = Cl[(r <= cl ? tri(r, cl) : tri(cl, r)) * 64];
-            }
-        }
         if (a.d_acceptance_rate) a.d_acceptance_rate[c] = rate;
-        if (a.d_status) a.d_status[c] = status;
+        if (a.d_status) a.d_status[c] = sync_ok ? status : (MCMC_CHAIN_SYNC_LOST | (n_iter << 4));
         if (a.d_shape_iterations) a.d_shape_iterations[c] = n_shape;
     }
 }
