@@ -156,20 +156,20 @@ __device__ __forceinline__ double fm_exp(double x)
 __device__ __forceinline__ void fm_sincospi_quarter(double r, double &s, double &c)
 {
     const double t = r * r;
-    double ps = 0.000461531855383581;
-    ps = fma(ps, t, -0.007370021586907771);
-    ps = fma(ps, t, 0.08214586918000175);
-    ps = fma(ps, t, -0.5992645289396449);
-    ps = fma(ps, t, 2.5501640398733763);
-    ps = fma(ps, t, -5.167712780049954);
-    ps = fma(ps, t, 3.141592653589793);
-    double pc = -0.00010356747255199479;
-    pc = fma(pc, t, 0.0019294657440800042);
-    pc = fma(pc, t, -0.025806885652951306);
-    pc = fma(pc, t, 0.23533063019088787);
-    pc = fma(pc, t, -1.3352627688519174);
-    pc = fma(pc, t, 4.058712126416747);
-    pc = fma(pc, t, -4.934802200544679);
+    double ps = sconst(0.000461531855383581, t);
+    ps = fma(ps, t, sconst(-0.007370021586907771, ps));
+    ps = fma(ps, t, sconst(0.08214586918000175, ps));
+    ps = fma(ps, t, sconst(-0.5992645289396449, ps));
+    ps = fma(ps, t, sconst(2.5501640398733763, ps));
+    ps = fma(ps, t, sconst(-5.167712780049954, ps));
+    ps = fma(ps, t, sconst(3.141592653589793, ps));
+    double pc = sconst(-0.00010356747255199479, t);
+    pc = fma(pc, t, sconst(0.0019294657440800042, pc));
+    pc = fma(pc, t, sconst(-0.025806885652951306, pc));
+    pc = fma(pc, t, sconst(0.23533063019088787, pc));
+    pc = fma(pc, t, sconst(-1.3352627688519174, pc));
+    pc = fma(pc, t, sconst(4.058712126416747, pc));
+    pc = fma(pc, t, sconst(-4.934802200544679, pc));
     pc = fma(pc, t, 1.0);
     s = r * ps;
     c = pc;

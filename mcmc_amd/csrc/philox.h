@@ -68,7 +68,11 @@ __host__ __device__ inline double u01_from_bits(uint32_t hi, uint32_t lo)
 #else
     __builtin_memcpy(&f, &bits, sizeof f);
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+    return f - sconst(0.99999999999999988897769753748, f); // f - (1 - 2^-53), exact
+#else
     return f - 0.99999999999999988897769753748; // f - (1 - 2^-53), exact
+#endif
 }
 
 struct PhiloxKey {

@@ -117,7 +117,7 @@ def test_batch_lane_kernel_injected(cuda, oracle, d, n_chains, n_sweeps):
         np.testing.assert_allclose(out["m2"].cpu().numpy()[:, c], ((want - want.mean(0)) ** 2).sum(0), rtol=1e-10)
 
 
-@pytest.mark.parametrize("d,n_chains,n_sweeps", [(24, 100, 60), (128, 70, 12)])
+@pytest.mark.parametrize("d,n_chains,n_sweeps", [(24, 100, 60), (33, 300, 20), (64, 130, 15), (128, 70, 12), (200, 65, 5)])
 def test_batch_lds_kernel_injected(cuda, oracle, d, n_chains, n_sweeps):
     import mcmc_amd
 
@@ -244,3 +244,41 @@ def test_argument_validation(cuda):
         mcmc_amd.tmvn_gibbs_batch(8, 5, mu, bad, lower, upper, init)
     with pytest.raises(mcmc_amd.McmcError):
         mcmc_amd.tmvn_gibbs_batch(8, 0, mu, sigma, lower, upper, init)
+
+
+def test_wide_kernel_philox_replay_sharding_thinning_and_tail(cuda, oracle):
+    """The d > 32 kernel (draw / dot wavefront pairs, rows staged through LDS): a Philox run replayed through
+    the oracle, invariance to sharding and thinning, and the tail-safe path with running moments only."""
+    import mcmc_amd
+
+    d, n_chains, n_sweeps = 48, 200, 12
+    mu, sigma, lower, upper, init = _c3_params(d, rho=0.4)
+    mu = mu + 0.05 * np.arange(d)
+    out = mcmc_amd.tmvn_gibbs_batch(n_chains, n_sweeps, mu, sigma, lower, upper, init, seed=21, chain_offset=9)
+    U = mcmc_amd.gibbs_streams(21, n_chains, n_sweeps, d, chain_offset=9).cpu().numpy()
+    trace = out["trace"].cpu().numpy()
+    for c in (0, 63, 64, 199):
+        want = oracle.rtmvnorm_gibbs(n_sweeps, mu, sigma, lower, upper, init, U[:, :, c].reshape(-1))
+        assert np.max(np.abs(trace[:, :, c] - want) / np.maximum(1.0, np.abs(want))) < RTOL
+    part = mcmc_amd.tmvn_gibbs_batch(72, n_sweeps, mu, sigma, lower, upper, init, seed=21, chain_offset=9 + 128)["trace"]
+    assert cuda.equal(out["trace"][:, :, 128:], part)
+    thin = mcmc_amd.tmvn_gibbs_batch(n_chains, n_sweeps, mu, sigma, lower, upper, init, seed=21, chain_offset=9, thin=5)["trace"]
+    assert thin.shape[0] == 2 and cuda.equal(thin, out["trace"][4::5][:2])
+    # C5 shape in small: lower = +4 conditional sd, upper = +Inf, tail-safe draw, last state + moments only
+    d = 128
+    sigma = 0.3 ** np.abs(np.arange(d)[:, None] - np.arange(d)[None, :])
+    _, sd_c = mcmc_amd.tmvn_precompute(sigma)
+    lower, upper = 4.0 * sd_c, np.full(d, np.inf)
+    o = mcmc_amd.tmvn_gibbs_batch(130, 30, np.zeros(d), sigma, lower, upper, lower + 0.1, seed=5, tail_safe=True, trace=False,
+                                  moments=True, burn=10)
+    assert np.all(o["status"].cpu().numpy() == 0)
+    fin = o["final_state"].cpu().numpy()
+    assert np.all(np.isfinite(fin)) and np.all(fin >= lower[:, None])
+    m = o["mean"].cpu().numpy()
+    assert np.all(m >= lower[:, None]) and np.all(m < lower[:, None] + 1.0)  # mass sits just above the bound
+    # the same run with the trace kept gives the same last state and the same running moments
+    o2 = mcmc_amd.tmvn_gibbs_batch(130, 30, np.zeros(d), sigma, lower, upper, lower + 0.1, seed=5, tail_safe=True, moments=True,
+                                   burn=10)
+    assert cuda.equal(o2["final_state"], o["final_state"]) and cuda.equal(o2["mean"], o["mean"])
+    tr = o2["trace"][10:].cpu().numpy()
+    np.testing.assert_allclose(m, tr.mean(axis=0), rtol=1e-12)
