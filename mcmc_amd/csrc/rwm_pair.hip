@@ -10,20 +10,27 @@
 // (:174-175), the (i-1)/i and 1/i factors of update_sigma (:43) -- is 40 % of the instructions and has
 // no dependence on the chain state.
 //
-// Layout.  A workgroup is 8 wavefronts = 256 chains: waves 0..3 sample chain groups 0..3, wave 4+g
-// generates for group g one iteration ahead and hands over through a 6 KB LDS buffer between two
-// adjacent barriers.  On MI355X wave w and wave w+4 of a workgroup are placed on the same SIMD
+// Layout.  A workgroup is 8 wavefronts = 256 chains: waves 0..3 sample chain groups 0..3, wave 4+g is
+// the generator of group g.  On MI355X wave w and wave w+4 of a workgroup are placed on the same SIMD
 // (tools/probe_hwid.hip, measured on all workgroups), so every SIMD holds one sampler and its own
-// generator, whose instructions fill the sampler's issue gaps.  One workgroup per CU (LDS 155 KB at
-// d = 10: covmat_empirical and theta_mean as [element][lane] per group).
+// generator, whose instructions fill the sampler's issue gaps.  One workgroup per CU (LDS 157 KB at
+// d = 10).  Per group, in LDS as [element][lane]: the draws of one iteration (generator -> sampler),
+// theta of the finished iteration (sampler -> generator) and covmat_empirical.
+//
+// Division of work.  The generator draws one iteration ahead, and it also owns update_sigma (:42-45) and
+// theta_mean (:212): it takes theta_i from the sampler and updates covmat_empirical in LDS while the
+// sampler is already in iteration i+1.  The sampler reads covmat_empirical only in iterations in which
+// one of its lanes factors it (shape phase), after waiting for the generator's "C_i complete" counter.
+// The two waves synchronise through monotone counters in LDS (no workgroup barrier: the four pairs of a
+// workgroup need different numbers of hand-shakes per iteration); every wait is bounded.
 //
 // What is done differently from the reference, results equal up to rounding:
 //   * chol(s^2 Sigma) = s chol(Sigma): the kernel keeps the UNSCALED factor R (chol(covmat) in the size
 //     phase, chol(covmat_empirical) in the shape phase) and the scale s apart, so the size phase needs
 //     no factorization at all (the reference refactors s^2 covmat every iteration, :129,153) and the
 //     shape phase factors covmat_empirical itself; the proposal is theta + s (Y R);
-//   * update_sigma (:43) as C (i-1)/i + ((i-1)/i^2 r_a) r_b, one FMA per element; the factorization of
-//     iteration i+1 consumes each updated element from the register it is in (loop rotated);
+//   * update_sigma (:43) as C (i-1)/i + ((i-1)/i^2 r_a) r_b, one FMA per element; the loop is rotated so
+//     that the adaptation and factorization for iteration i+1 close iteration i;
 //   * mvrnorm_pdf (:48-64) from det = (s^d prod diag R)^2 and v^T Sigma^-1 v = |Y|^2, still evaluated
 //     as log(rootTerm exp(-q/2)), added and subtracted, so the (la + p) - p rounding and the NaN
 //     reject path survive;
