@@ -12,60 +12,60 @@
 
 namespace mcmc {
 
+// Horner step with the coefficient delivered through a scalar register pair at its use (fastmath.h: sconst)
+__device__ __forceinline__ double hstep(double acc, double x, double c) { return fma(acc, x, sconst(c, acc)); }
+
 // lower-tail standard normal CDF, Cody's three ranges (|x| <= 0.67448975, <= sqrt(32), tails
-// cut at -37.5193 / +8.2924 exactly as R does for the lower tail).
+// cut at -37.5193 / +8.2924 exactly as R does for the lower tail).  Cody writes the rational functions as
+// repeated (acc + c) * x; here they are the same polynomials in Horner form, one FMA per coefficient.
 __device__ inline double pnorm_std(double x)
 {
     const double y = fabs(x);
-    if (y <= 0.67448975) {
-        double xnum = 0.0, xden = 0.0;
-        if (y > 1.1102230246251565e-16) {
-            const double xsq = x * x;
-            xnum = 0.065682337918207449113 * xsq;
-            xden = xsq;
-            xnum = (xnum + 2.2352520354606839287) * xsq;
-            xden = (xden + 47.20258190468824187) * xsq;
-            xnum = (xnum + 161.02823106855587881) * xsq;
-            xden = (xden + 976.09855173777669322) * xsq;
-            xnum = (xnum + 1067.6894854603709582) * xsq;
-            xden = (xden + 10260.932208618978205) * xsq;
-        }
-        const double temp = x * fm_div(xnum + 18154.981253343561249, xden + 45507.789335026729956);
-        return 0.5 + temp;
+    if (y <= 0.67448975) { // for |x| < 1.1e-16 (where R sets both sums to 0) x^2 underflows harmlessly: same value
+        const double xsq = x * x;
+        double xnum = fma(sconst(0.065682337918207449113, xsq), xsq, sconst(2.2352520354606839287, xsq));
+        xnum = hstep(xnum, xsq, 161.02823106855587881);
+        xnum = hstep(xnum, xsq, 1067.6894854603709582);
+        xnum = hstep(xnum, xsq, 18154.981253343561249);
+        double xden = xsq + sconst(47.20258190468824187, xsq);
+        xden = hstep(xden, xsq, 976.09855173777669322);
+        xden = hstep(xden, xsq, 10260.932208618978205);
+        xden = hstep(xden, xsq, 45507.789335026729956);
+        return 0.5 + x * fm_div(xnum, xden);
     }
     double temp;
     if (y <= 5.656854249492380195206754896838) {
-        double xnum = 1.0765576773720192317e-8 * y;
-        double xden = y;
-        xnum = (xnum + 0.39894151208813466764) * y;
-        xden = (xden + 22.266688044328115691) * y;
-        xnum = (xnum + 8.8831497943883759412) * y;
-        xden = (xden + 235.38790178262499861) * y;
-        xnum = (xnum + 93.506656132177855979) * y;
-        xden = (xden + 1519.377599407554805) * y;
-        xnum = (xnum + 597.27027639480026226) * y;
-        xden = (xden + 6485.558298266760755) * y;
-        xnum = (xnum + 2494.5375852903726711) * y;
-        xden = (xden + 18615.571640885098091) * y;
-        xnum = (xnum + 6848.1904505362823326) * y;
-        xden = (xden + 34900.952721145977266) * y;
-        xnum = (xnum + 11602.651437647350124) * y;
-        xden = (xden + 38912.003286093271411) * y;
-        temp = fm_div(xnum + 9842.7148383839780218, xden + 19685.429676859990727);
+        double xnum = fma(sconst(1.0765576773720192317e-8, y), y, sconst(0.39894151208813466764, y));
+        xnum = hstep(xnum, y, 8.8831497943883759412);
+        xnum = hstep(xnum, y, 93.506656132177855979);
+        xnum = hstep(xnum, y, 597.27027639480026226);
+        xnum = hstep(xnum, y, 2494.5375852903726711);
+        xnum = hstep(xnum, y, 6848.1904505362823326);
+        xnum = hstep(xnum, y, 11602.651437647350124);
+        xnum = hstep(xnum, y, 9842.7148383839780218);
+        double xden = y + sconst(22.266688044328115691, y);
+        xden = hstep(xden, y, 235.38790178262499861);
+        xden = hstep(xden, y, 1519.377599407554805);
+        xden = hstep(xden, y, 6485.558298266760755);
+        xden = hstep(xden, y, 18615.571640885098091);
+        xden = hstep(xden, y, 34900.952721145977266);
+        xden = hstep(xden, y, 38912.003286093271411);
+        xden = hstep(xden, y, 19685.429676859990727);
+        temp = fm_div(xnum, xden);
     } else if (-37.5193 < x && x < 8.2924) {
         const double xsq = fm_rcp(x * x);
-        double xnum = 0.02307344176494017303 * xsq;
-        double xden = xsq;
-        xnum = (xnum + 0.21589853405795699) * xsq;
-        xden = (xden + 1.28426009614491121) * xsq;
-        xnum = (xnum + 0.1274011611602473639) * xsq;
-        xden = (xden + 0.468238212480865118) * xsq;
-        xnum = (xnum + 0.022235277870649807) * xsq;
-        xden = (xden + 0.0659881378689285515) * xsq;
-        xnum = (xnum + 0.001421619193227893466) * xsq;
-        xden = (xden + 0.00378239633202758244) * xsq;
-        temp = xsq * fm_div(xnum + 2.9112874951168792e-5, xden + 7.29751555083966205e-5);
-        temp = fm_div(0.398942280401432677939946059934 - temp, y);
+        double xnum = fma(sconst(0.02307344176494017303, xsq), xsq, sconst(0.21589853405795699, xsq));
+        xnum = hstep(xnum, xsq, 0.1274011611602473639);
+        xnum = hstep(xnum, xsq, 0.022235277870649807);
+        xnum = hstep(xnum, xsq, 0.001421619193227893466);
+        xnum = hstep(xnum, xsq, 2.9112874951168792e-5);
+        double xden = xsq + sconst(1.28426009614491121, xsq);
+        xden = hstep(xden, xsq, 0.468238212480865118);
+        xden = hstep(xden, xsq, 0.0659881378689285515);
+        xden = hstep(xden, xsq, 0.00378239633202758244);
+        xden = hstep(xden, xsq, 7.29751555083966205e-5);
+        temp = xsq * fm_div(xnum, xden);
+        temp = fm_div(sconst(0.398942280401432677939946059934, temp) - temp, y);
     } else {
         return (x > 0) ? 1.0 : 0.0;
     }
@@ -74,7 +74,7 @@ __device__ inline double pnorm_std(double x)
     // the lo part applied to first order (|lo| < 2^-43), which is as accurate and needs one exp.
     const double hi = y * y;
     const double lo = fma(y, y, -hi);
-    const double E = exp(-0.5 * hi);
+    const double E = fm_exp(-0.5 * hi);
     const double cum = fma(-0.5 * lo, E, E) * temp;
     return (x > 0.) ? 1.0 - cum : cum;
 }
@@ -103,32 +103,59 @@ __device__ inline double qnorm_std(double p)
     const double q = p - 0.5;
     if (fabs(q) <= 0.425) {
         const double r = .180625 - q * q;
-        return q * (((((((r * 2509.0809287301226727 + 33430.575583588128105) * r + 67265.770927008700853) * r +
-                        45921.953931549871457) * r + 13731.693765509461125) * r + 1971.5909503065514427) * r +
-                     133.14166789178437745) * r + 3.387132872796366608) *
-               fm_rcp(((((((r * 5226.495278852854561 + 28729.085735721942674) * r + 39307.89580009271061) * r +
-                    21213.794301586595867) * r + 5394.1960214247511077) * r + 687.1870074920579083) * r +
-                 42.313330701600911252) * r + 1.);
+        double num = fma(sconst(2509.0809287301226727, r), r, sconst(33430.575583588128105, r));
+        num = hstep(num, r, 67265.770927008700853);
+        num = hstep(num, r, 45921.953931549871457);
+        num = hstep(num, r, 13731.693765509461125);
+        num = hstep(num, r, 1971.5909503065514427);
+        num = hstep(num, r, 133.14166789178437745);
+        num = hstep(num, r, 3.387132872796366608);
+        double den = fma(sconst(5226.495278852854561, r), r, sconst(28729.085735721942674, r));
+        den = hstep(den, r, 39307.89580009271061);
+        den = hstep(den, r, 21213.794301586595867);
+        den = hstep(den, r, 5394.1960214247511077);
+        den = hstep(den, r, 687.1870074920579083);
+        den = hstep(den, r, 42.313330701600911252);
+        den = fma(den, r, 1.0);
+        return q * num * fm_rcp(den);
     }
     double r = (q < 0) ? p : 1.0 - p;
     r = fm_sqrt(-fm_log<false>(r));
     double val;
     if (r <= 5.) {
         r += -1.6;
-        val = (((((((r * 7.7454501427834140764e-4 + .0227238449892691845833) * r + .24178072517745061177) * r +
-                   1.27045825245236838258) * r + 3.64784832476320460504) * r + 5.7694972214606914055) * r +
-                4.6303378461565452959) * r + 1.42343711074968357734) *
-              fm_rcp(((((((r * 1.05075007164441684324e-9 + 5.475938084995344946e-4) * r + .0151986665636164571966) * r +
-                   .14810397642748007459) * r + .68976733498510000455) * r + 1.6763848301838038494) * r +
-                2.05319162663775882187) * r + 1.);
+        double num = fma(sconst(7.7454501427834140764e-4, r), r, sconst(.0227238449892691845833, r));
+        num = hstep(num, r, .24178072517745061177);
+        num = hstep(num, r, 1.27045825245236838258);
+        num = hstep(num, r, 3.64784832476320460504);
+        num = hstep(num, r, 5.7694972214606914055);
+        num = hstep(num, r, 4.6303378461565452959);
+        num = hstep(num, r, 1.42343711074968357734);
+        double den = fma(sconst(1.05075007164441684324e-9, r), r, sconst(5.475938084995344946e-4, r));
+        den = hstep(den, r, .0151986665636164571966);
+        den = hstep(den, r, .14810397642748007459);
+        den = hstep(den, r, .68976733498510000455);
+        den = hstep(den, r, 1.6763848301838038494);
+        den = hstep(den, r, 2.05319162663775882187);
+        den = fma(den, r, 1.0);
+        val = num * fm_rcp(den);
     } else {
         r += -5.;
-        val = (((((((r * 2.01033439929228813265e-7 + 2.71155556874348757815e-5) * r + .0012426609473880784386) * r +
-                   .026532189526576123093) * r + .29656057182850489123) * r + 1.7848265399172913358) * r +
-                5.4637849111641143699) * r + 6.6579046435011037772) *
-              fm_rcp(((((((r * 2.04426310338993978564e-15 + 1.4215117583164458887e-7) * r + 1.8463183175100546818e-5) * r +
-                   7.868691311456132591e-4) * r + .0148753612908506148525) * r + .13692988092273580531) * r +
-                .59983220655588793769) * r + 1.);
+        double num = fma(sconst(2.01033439929228813265e-7, r), r, sconst(2.71155556874348757815e-5, r));
+        num = hstep(num, r, .0012426609473880784386);
+        num = hstep(num, r, .026532189526576123093);
+        num = hstep(num, r, .29656057182850489123);
+        num = hstep(num, r, 1.7848265399172913358);
+        num = hstep(num, r, 5.4637849111641143699);
+        num = hstep(num, r, 6.6579046435011037772);
+        double den = fma(sconst(2.04426310338993978564e-15, r), r, sconst(1.4215117583164458887e-7, r));
+        den = hstep(den, r, 1.8463183175100546818e-5);
+        den = hstep(den, r, 7.868691311456132591e-4);
+        den = hstep(den, r, .0148753612908506148525);
+        den = hstep(den, r, .13692988092273580531);
+        den = hstep(den, r, .59983220655588793769);
+        den = fma(den, r, 1.0);
+        val = num * fm_rcp(den);
     }
     return (q < 0.0) ? -val : val;
 }
