@@ -113,12 +113,66 @@ __global__ __launch_bounds__(64, 3) void gibbs_kernel(const GibbsArgs a, const d
 // The rows are shared by the workgroup: every thread fetches one or two values of row i+2 (P and the
 // five scalars, coalesced) while step i runs and drops them into a three-slot LDS ring before the
 // single barrier that ends the step; the barrier waits for LDS traffic only, so trace and moment
-// stores stay in flight.  The running moments of the next coordinate are prefetched the same way.
+// stores stay in flight.  Running moments are kept as sums of the centred draw and its square, added to
+// HBM with no-return atomics (each lane owns its addresses) and turned into mean / M2 once at the end.
 // The sum is associated differently from the reference's left-to-right loop
 // (tmvrnormGibbs.cpp:124-127): the x_(i-1) term is added last.
 //
 // rows block in HBM: d rows of W doubles: P_i padded to d entries (entry i is 0 and never read), mu_i,
 // sd_i, 1/sd_i, lower_i, upper_i; then init[d].
+// s + sum_{k0 <= k < k1} row[k] * xc[k], row read as same-address (broadcast) LDS loads, xc as [k][lane].
+// Software pipelined by hand: the sixteen LDS loads of the next eight terms are issued before the eight
+// FMAs of the current ones, so a lone wave (this kernel runs one wave per SIMD) does not sit out an LDS
+// round trip per group of terms.
+__device__ __forceinline__ double dot_range(const double *row, const double *xc, int k0, int k1, double s)
+{
+    constexpr int CH = 8;
+    int k = k0;
+    if (k1 - k >= CH) {
+        double ra[CH], xa[CH], rb[CH], xb[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            ra[u] = row[k + u];
+            xa[u] = xc[(k + u) * 64];
+        }
+        k += CH;
+        while (k1 - k >= 2 * CH) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                rb[u] = row[k + u];
+                xb[u] = xc[(k + u) * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) s = fma(ra[u], xa[u], s);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                ra[u] = row[k + CH + u];
+                xa[u] = xc[(k + CH + u) * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) s = fma(rb[u], xb[u], s);
+            k += 2 * CH;
+        }
+        if (k1 - k >= CH) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                rb[u] = row[k + u];
+                xb[u] = xc[(k + u) * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) s = fma(ra[u], xa[u], s);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) s = fma(rb[u], xb[u], s);
+            k += CH;
+        } else {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) s = fma(ra[u], xa[u], s);
+        }
+    }
+    for (; k < k1; ++k) s = fma(row[k], xc[k * 64], s);
+    return s;
+}
+
 constexpr int kWideMaxPrefetch = 3; // ceil(W / threads) at d = 256 (one group, 128 threads)
 
 template <bool TAIL_SAFE, bool MOMENTS>
@@ -156,23 +210,20 @@ __global__ __launch_bounds__(512) void gibbs_wide_kernel(const GibbsArgs a, cons
     for (int e = tid; e < 2 * W; e += nthreads) ring[e] = rows[e];
     __syncthreads();
 
+    double ua = 0.0, ub = 0.0; // the two uniforms of the current Philox block (dot wave)
     // what the dot wave leaves for coordinate i of sweep j in slot parity p
     auto prepare = [&](int i, int j, const double *row, int p) {
         const int skip = (i == 0) ? d - 1 : i - 1; // the element the draw wave is still changing
         const int lo = skip < i ? skip : i, hi = skip < i ? i : skip; // d >= 3: two distinct indices
-        double s = 0.0;
-#pragma unroll 8
-        for (int k = 0; k < lo; ++k) s += row[k] * xc[k * 64];
-#pragma unroll 8
-        for (int k = lo + 1; k < hi; ++k) s += row[k] * xc[k * 64];
-#pragma unroll 8
-        for (int k = hi + 1; k < d; ++k) s += row[k] * xc[k * 64];
+        double s = dot_range(row, xc, 0, lo, 0.0);
+        s = dot_range(row, xc, lo + 1, hi, s);
+        s = dot_range(row, xc, hi + 1, d, s);
         double u;
         if (a.d_U) {
             u = a.d_U[((int64_t)(j - 1) * d + i) * n + cc];
         } else {
-            double ua, ub;
-            philox_uniform2(PhiloxKey(a.seed), (uint64_t)(a.chain_offset + cc), (uint32_t)j, TAG_GIBBS, (uint32_t)(i >> 1), ua, ub);
+            if ((i & 1) == 0) // coordinates are prepared in order, so the odd one finds its uniform waiting
+                philox_uniform2(PhiloxKey(a.seed), (uint64_t)(a.chain_offset + cc), (uint32_t)j, TAG_GIBBS, (uint32_t)(i >> 1), ua, ub);
             u = (i & 1) ? ub : ua;
         }
         slot[(p * 2 + 0) * 64] = s;
@@ -183,7 +234,6 @@ __global__ __launch_bounds__(512) void gibbs_wide_kernel(const GibbsArgs a, cons
     lds_barrier();
 
     int32_t status = MCMC_CHAIN_OK;
-    double cm = 0.0, cq = 0.0; // running mean / M2 of the current coordinate (prefetched)
     double xprev = dotter ? 0.0 : xc[(d - 1) * 64]; // centred x of the previous coordinate
     int i = 0, j = 1, r0 = 0;  // coordinate, sweep, ring slot of row i
     for (int64_t t = 0; t < total; ++t) {
@@ -201,11 +251,6 @@ __global__ __launch_bounds__(512) void gibbs_wide_kernel(const GibbsArgs a, cons
             if (t + 1 < total) prepare(i1, i1 == 0 ? j + 1 : j, ring + r1 * W, p ^ 1);
         } else {
             const double *const row = ring + r0 * W;
-            double nm = 0.0, nq = 0.0;
-            if (MOMENTS && live) {
-                nm = a.d_mean[(int64_t)i1 * n + c];
-                nq = a.d_m2[(int64_t)i1 * n + c];
-            }
             const bool keep = a.d_trace && (j % a.thin) == 0;
             const bool mom = MOMENTS && j > a.burn;
             // conditional mean mu_i + P_i (x[-i] - mu[-i])   (tmvrnormGibbs.cpp:124-127)
@@ -220,16 +265,11 @@ __global__ __launch_bounds__(512) void gibbs_wide_kernel(const GibbsArgs a, cons
             if (live) {
                 if (keep) a.d_trace[((int64_t)(j / a.thin - 1) * d + i) * n + c] = xi;
                 if (j == a.n_sweeps && a.d_final) a.d_final[(int64_t)i * n + c] = xi;
-                if (mom) {
-                    const double inv = 1.0 / (double)(j - a.burn);
-                    const double delta = xi - cm;
-                    const double mean = cm + delta * inv;
-                    a.d_mean[(int64_t)i * n + c] = mean;
-                    a.d_m2[(int64_t)i * n + c] = cq + delta * (xi - mean);
+                if (mom) { // running sums of the centred draw; no value comes back, so nothing waits for HBM
+                    unsafeAtomicAdd(a.d_mean + (int64_t)i * n + c, xprev);
+                    unsafeAtomicAdd(a.d_m2 + (int64_t)i * n + c, xprev * xprev);
                 }
             }
-            cm = nm;
-            cq = nq;
         }
         // row i+2 goes into the free ring slot (it held row i-1, last read one step ago)
         double *const nxt = ring + r2 * W;
@@ -243,7 +283,19 @@ __global__ __launch_bounds__(512) void gibbs_wide_kernel(const GibbsArgs a, cons
         i = i1;
         if (i == 0) ++j;
     }
-    if (!dotter && live && a.d_status) a.d_status[c] = status;
+    if (!dotter && live) {
+        if (a.d_status) a.d_status[c] = status;
+        if (MOMENTS) { // sums of (x - mu_k), (x - mu_k)^2 over the kept sweeps -> mean and M2 (sum of squared deviations)
+            __threadfence();
+            const int nm = a.n_sweeps - a.burn;
+            const double inv = nm > 0 ? 1.0 / (double)nm : 0.0;
+            for (int k = 0; k < d; ++k) {
+                const double s1 = a.d_mean[(int64_t)k * n + c], s2 = a.d_m2[(int64_t)k * n + c];
+                a.d_mean[(int64_t)k * n + c] = rows[(size_t)k * W + d] + s1 * inv;
+                a.d_m2[(int64_t)k * n + c] = fma(-s1 * inv, s1, s2);
+            }
+        }
+    }
 }
 
 // uniforms a Philox Gibbs run draws, [n_sweeps][d][n_chains]

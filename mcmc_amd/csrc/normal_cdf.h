@@ -18,7 +18,7 @@ __device__ __forceinline__ double hstep(double acc, double x, double c) { return
 // lower-tail standard normal CDF, Cody's three ranges (|x| <= 0.67448975, <= sqrt(32), tails
 // cut at -37.5193 / +8.2924 exactly as R does for the lower tail).  Cody writes the rational functions as
 // repeated (acc + c) * x; here they are the same polynomials in Horner form, one FMA per coefficient.
-__device__ inline double pnorm_std(double x)
+__device__ __forceinline__ double pnorm_std(double x)
 {
     const double y = fabs(x);
     if (y <= 0.67448975) { // for |x| < 1.1e-16 (where R sets both sums to 0) x^2 underflows harmlessly: same value
@@ -94,7 +94,7 @@ __device__ inline double pnorm(double x, double mu, double sigma)
 }
 
 // R::qnorm(p, 0, 1, lower = 1, log = 0): AS241
-__device__ inline double qnorm_std(double p)
+__device__ __forceinline__ double qnorm_std(double p)
 {
     if (isnan(p)) return p;
     if (p < 0 || p > 1) return __builtin_nan("");
@@ -168,7 +168,7 @@ __device__ inline double qnorm_std(double p)
 //       Qb = Phi((mu_i-upper)/sd); algebraically identical, but Qa, Qb do not round to 1, so bounds
 //       more than ~8.3 sd out (where the reference returns +Inf) still give finite draws.
 template <bool TAIL_SAFE>
-__device__ inline double rtnorm_draw(double u, double mu_i, double sd, double lower, double upper)
+__device__ __forceinline__ double rtnorm_draw(double u, double mu_i, double sd, double lower, double upper)
 {
     if (TAIL_SAFE && lower > mu_i) {
         const double Qa = pnorm_std((mu_i - lower) / sd); // P(X > lower)
@@ -184,7 +184,7 @@ __device__ inline double rtnorm_draw(double u, double mu_i, double sd, double lo
 // the Gibbs kernels, where sd > 0 is guaranteed by the host and 1/sd is a shared parameter;
 // -Inf / +Inf bounds fall through pnorm_std to exactly 0 / 1 as in R's pnorm.
 template <bool TAIL_SAFE>
-__device__ inline double rtnorm_draw_std(double u, double mu_i, double sd, double inv_sd, double lower, double upper)
+__device__ __forceinline__ double rtnorm_draw_std(double u, double mu_i, double sd, double inv_sd, double lower, double upper)
 {
     const double a = (lower - mu_i) * inv_sd;
     const double b = (upper - mu_i) * inv_sd;
