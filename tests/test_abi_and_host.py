@@ -142,3 +142,25 @@ def test_missing_library_fails_loudly(tmp_path):
         "sys.exit(1)\n")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode == 0 and "IMPORTERROR" in r.stdout and "no CPU fallback" in r.stdout
+
+
+def test_melt_trace_matches_the_reference_layout():
+    """melt_trace (MCMCutilty.R:19-35): parameters, then `chain` (1-based factor) and `iteration`, stacked chain by chain."""
+    import mcmc_amd
+
+    rng = np.random.default_rng(0)
+    tr = rng.standard_normal((5, 3, 4))  # [n_kept, d, n_chains]
+    chains = mcmc_amd.chain_list(tr, ["a", "b", "c"], acceptance_rate=np.array([0.1, 0.2, 0.3, 0.4]))
+    assert len(chains) == 4 and chains[2]["trace"].shape == (5, 3) and chains[3]["acceptance_rate"] == 0.4
+    df = mcmc_amd.melt_trace(chains)
+    assert list(df.columns) == ["a", "b", "c", "chain", "iteration"] and len(df) == 20
+    np.testing.assert_array_equal(df["iteration"].to_numpy(), np.tile(np.arange(1, 6), 4))
+    np.testing.assert_array_equal(np.asarray(df["chain"]), np.repeat(np.arange(1, 5), 5))
+    np.testing.assert_array_equal(df[["a", "b", "c"]].to_numpy()[5:10], tr[:, :, 1])
+    assert str(df["chain"].dtype) == "category"
+    # default column names are R's V1..Vd; a subset of chains can be selected before the host copy
+    sub = mcmc_amd.chain_list(tr, chains=[3, 0])
+    assert sub[0]["par_names"] == ["V1", "V2", "V3"]
+    np.testing.assert_array_equal(sub[0]["trace"], tr[:, :, 3])
+    with pytest.raises(ValueError):
+        mcmc_amd.melt_trace([])

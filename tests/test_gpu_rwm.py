@@ -385,3 +385,22 @@ def test_paired_wave_kernel_targets_thinning_and_failure(cuda, oracle):
     # requests the paired-wave kernel does not serve are refused, not silently rerouted
     with pytest.raises(mcmc_amd.McmcError):
         mcmc_amd.adapt_rwm_batch(tgt, 4, np.zeros(d), np.eye(d), 10, diagnostics=True, kernel="pair")
+
+
+def test_run_chains_gives_the_list_of_chains_melt_trace_expects(cuda, oracle):
+    """run_chains = the job of mclapply_RNG(X, adaptMCMC ...) (MCMCutilty.R:103-149) in one launch."""
+    import mcmc_amd
+
+    d, n = 3, 200
+    Sig, H = _gauss(d, 0.5)
+    tgt = mcmc_amd.Target.gaussian(np.zeros(d), H)
+    X = [[0.0, 0.0, 0.0], [1.0, -1.0, 0.5], [2.0, 2.0, 2.0]]
+    chains = mcmc_amd.run_chains(X, tgt, np.eye(d), n, 20, 0.0, 0, 60, seed=4, par_names=["x", "y", "z"])
+    assert len(chains) == 3 and all(c["status"] == 0 for c in chains)
+    df = mcmc_amd.melt_trace(chains)
+    assert df.shape == (3 * n, 5)
+    Z, U = mcmc_amd.rwm_streams(4, 3, n, d)
+    ref = oracle.adaptMCMC(oracle.gaussian_target(np.zeros(d), H), X[1], np.eye(d), n, 20, 0.0, 0, 60, Z.cpu().numpy()[:, :, 1],
+                           U.cpu().numpy()[:, 1], store_sigma=False)
+    assert _rel(chains[1]["trace"], ref["theta_trace"]) < RTOL
+    assert chains[1]["acceptance_rate"] == ref["acceptance_rate"]
