@@ -87,3 +87,25 @@ if __name__ == "__main__" and "block" in sys.argv:
     rwm_block(128, 2048, 100)
     rwm_block(32, 8192, 200)
     rwm_block(16, 16384, 200)
+
+
+def rwm_block_shape(d, chains, iters):
+    """shape phase from the first iterations on: small covmat, shape start right after d accepted jumps"""
+    rng = np.random.default_rng(4)
+    A = rng.standard_normal((d, d))
+    Sig = A @ A.T / d + np.eye(d)
+    H = np.linalg.inv(Sig); H = 0.5 * (H + H.T)
+    tgt = mcmc_amd.Target.gaussian(np.zeros(d), H)
+    f = lambda: mcmc_amd.adapt_rwm_batch(tgt, chains, np.zeros(d), (0.3 / d) * np.eye(d), iters, 0, 0.0, 0, 2 * d, seed=1, thin=10,
+                                         final=False)
+    ms = timeit(f, reps=2)
+    out = f()
+    frac = float(out["shape_iterations"].double().mean().item()) / iters
+    bad = int((out["status"] != 0).sum().item())
+    print(f"rwm-block-shape d={d} chains={chains} iters={iters}: {ms:.2f} ms  {chains*iters/(ms*1e-3):.3e} chain-iter/s  shape fraction {frac:.2f}  failed {bad}")
+
+
+if __name__ == "__main__" and "shape" in sys.argv:
+    rwm_block_shape(100, 3072, 1000)
+    rwm_block_shape(64, 3072, 1000)
+    rwm_block_shape(32, 6144, 1000)
