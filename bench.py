@@ -296,11 +296,15 @@ def main():
         else:
             flops_launch = units * gibbs_flops_per_sweep(d)
             kept = n_iter // thin if want_trace else 0
-            kernel = "gibbs_kernel"
+            kernel = "gibbs_kernel" if d <= 32 else "gibbs_wide_kernel"
             per_unit = {"flops_per_chain_sweep": gibbs_flops_per_sweep(d)}
             unit = "chain-sweeps/s"
             metric = "chain-iterations/sec (TMVN Gibbs sweeps, whole job)"
         bytes_launch = 8.0 * d * n_chains * kept
+        if not is_rwm and not want_trace:
+            # moments-only run: last state, mean and M2 leave the kernel once; the running sums themselves live in
+            # HBM (16 B read + 16 B written per chain, coordinate and counted sweep, mostly absorbed by L2 / MALL)
+            bytes_launch = 24.0 * d * n_chains
         achieved_tf = flops_launch / (kern_ms * 1e-3) / 1e12
         line = {
             "metric": metric,
