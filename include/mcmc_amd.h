@@ -28,7 +28,9 @@
 #ifndef MCMC_AMD_H
 #define MCMC_AMD_H
 
+#ifndef __HIPCC_RTC__ /* the run-time compiler (user targets) brings its own fixed-width types */
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -74,12 +76,41 @@ extern "C" {
 #define MCMC_TARGET_GAUSSIAN_PREC 0   /* -0.5 (x-m)^T H (x-m); params = m[d], H[d*d] column-major */
 #define MCMC_TARGET_GOLDSTEIN_PRICE 1 /* adaptMCMC_analysis.R:115-129 (d = 2); no params          */
 #define MCMC_TARGET_BANANA 2          /* adaptMCMC_analysis.R:19-22  (d = 2); params = B          */
+#define MCMC_TARGET_USER 3            /* a log-density supplied as HIP source, see mcmc_target_compile */
 
 typedef struct mcmc_target {
     int32_t kind;
     int32_t n_params;
     const double *h_params;
+    const void *user;              /* MCMC_TARGET_USER: handle from mcmc_target_compile; else NULL */
 } mcmc_target;
+
+/*
+ * User targets: the compiled-code replacement for an arbitrary R closure `target`
+ * (adaptMCMC_source.cpp:75,97,158).  `source` is HIP device code that defines
+ *
+ *     __device__ double mcmc_user_target(const double (&x)[MCMC_USER_D], const double *params);
+ *
+ * returning the log-density at x (any non-finite value rejects the proposal, :163-165).
+ * MCMC_USER_D (= d) and MCMC_USER_NP (= n_params) are predefined; `params` points at the
+ * n_params doubles of mcmc_target::h_params (shared by all chains, resident in LDS); the lean
+ * mcmc::fm_log / fm_exp / fm_sqrt_rsq of csrc/fastmath.h and the usual device math are available.
+ * The source is compiled for gfx950 with hipRTC together with the Metropolis kernels (d <= 12:
+ * one chain per lane), so the function is inlined into the sampling loop.  Needs the kernel
+ * sources at run time: <library dir>/csrc and <library dir>/../include, or $MCMC_AMD_SRC_DIR,
+ * $MCMC_AMD_INCLUDE_DIR; HIP headers from $ROCM_PATH (default /opt/rocm).
+ * On a compile error the call returns MCMC_E_BAD_ARG and `log` (capacity log_capacity, may be
+ * NULL) receives the compiler's diagnostics.  Compiling needs no GPU; the module is loaded on
+ * each device at first use.  Handles are immutable and may be shared between threads.
+ */
+int mcmc_target_compile(const char *source, int32_t d, int32_t n_params, void **handle,
+                        char *log, int64_t log_capacity);
+int mcmc_target_destroy(void *handle);
+/* log-density of `target` (any kind, d <= 12) at n points: d_x is [d][n], d_out is [n].  Lets a
+ * caller check a compiled target against its host definition before sampling.  No counterpart in
+ * the reference (there the closure can simply be called from R). */
+int mcmc_target_eval_batch(const mcmc_target *target, int32_t d, int64_t n, const double *d_x,
+                           double *d_out, void *stream);
 
 /* ----- library ----------------------------------------------------------------------- */
 int mcmc_amd_abi_version(void);

@@ -9,6 +9,6 @@ from ._lib import (  # noqa: F401
 )
 from .api import (  # noqa: F401
     Target, adaptMCMC, adapt_rwm_batch, gibbs_streams, init_normal, negSubCol, negSubRow, rtmvnorm_gibbs,
-    rtnorm_batch, rtnorm_gibbs, rwMCMC, rwm_streams, sub1, sub2, tmvn_gibbs_batch, tmvn_precompute,
+    rtnorm_batch, rtnorm_gibbs, rwMCMC, rwm_streams, sub1, sub2, target_eval_batch, tmvn_gibbs_batch, tmvn_precompute,
 )
 from .chains import chain_list, melt_trace, run_chains  # noqa: F401,E402

@@ -33,6 +33,7 @@ MCMC_KERNEL_PAIR = 3
 MCMC_TARGET_GAUSSIAN_PREC = 0
 MCMC_TARGET_GOLDSTEIN_PRICE = 1
 MCMC_TARGET_BANANA = 2
+MCMC_TARGET_USER = 3
 
 dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int32)
@@ -40,7 +41,7 @@ vp = C.c_void_p
 
 
 class McmcTarget(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("n_params", C.c_int32), ("h_params", dp)]
+    _fields_ = [("kind", C.c_int32), ("n_params", C.c_int32), ("h_params", dp), ("user", C.c_void_p)]
 
 
 class RwmConfig(C.Structure):
@@ -88,6 +89,9 @@ SIGNATURES = {
     "mcmc_amd_last_error": (C.c_char_p, []),
     "mcmc_amd_max_lane_dim": (C.c_int, []),
     "mcmc_amd_max_dim": (C.c_int, []),
+    "mcmc_target_compile": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.c_char_p, C.c_int64]),
+    "mcmc_target_destroy": (C.c_int, [vp]),
+    "mcmc_target_eval_batch": (C.c_int, [C.POINTER(McmcTarget), C.c_int32, C.c_int64, vp, vp, vp]),
     "mcmc_adapt_rwm_batch": (C.c_int, [C.POINTER(McmcTarget), C.POINTER(RwmConfig), C.POINTER(RwmIO), vp]),
     "mcmc_rwm_streams": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, vp, vp]),
     "mcmc_init_normal": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, C.c_int32, dp, C.c_double, vp, vp]),

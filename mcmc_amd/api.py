@@ -30,6 +30,7 @@ class Target:
     kind: int
     params: np.ndarray
     d: Optional[int] = None
+    _user: Optional["_UserHandle"] = None
 
     @staticmethod
     def gaussian(mean, precision) -> "Target":
@@ -50,11 +51,49 @@ class Target:
         """adaptMCMC_analysis.R:19-22"""
         return Target(L.MCMC_TARGET_BANANA, np.array([float(B)]), 2)
 
+    @staticmethod
+    def compile(source: str, d: int, params=()) -> "Target":
+        """A user log-density as HIP device source (mcmc_target_compile): the compiled-code
+        replacement for an arbitrary R closure `target` (adaptMCMC_source.cpp:75,97,158).
+
+        `source` defines
+            __device__ double mcmc_user_target(const double (&x)[MCMC_USER_D], const double *params)
+        and is compiled with hipRTC into the Metropolis kernels (d <= 12).  Raises McmcError with the
+        compiler's diagnostics if it does not compile."""
+        prm = np.ascontiguousarray(params, dtype=np.float64).reshape(-1)
+        handle = C.c_void_p()
+        log = C.create_string_buffer(1 << 16)
+        rc = lib.mcmc_target_compile(source.encode("utf-8"), int(d), int(prm.size), C.byref(handle), log, len(log))
+        if rc != L.MCMC_OK:
+            raise L.McmcError(rc, lib.mcmc_amd_last_error().decode("utf-8", "replace") + "\n"
+                              + log.value.decode("utf-8", "replace"))
+        return Target(L.MCMC_TARGET_USER, prm, int(d), _UserHandle(handle.value))
+
+    def with_params(self, params) -> "Target":
+        """The same compiled user target with other parameter values (same count)."""
+        prm = np.ascontiguousarray(params, dtype=np.float64).reshape(-1)
+        if prm.size != np.asarray(self.params).size:
+            raise ValueError("the number of parameters is fixed when the target is compiled")
+        return Target(self.kind, prm, self.d, self._user)
+
     def _c(self):
         prm = np.ascontiguousarray(self.params, dtype=np.float64)
-        t = L.McmcTarget(self.kind, prm.size, prm.ctypes.data_as(dp) if prm.size else None)
-        t._keep = prm
+        t = L.McmcTarget(self.kind, prm.size, prm.ctypes.data_as(dp) if prm.size else None,
+                         self._user.value if self._user is not None else None)
+        t._keep = (prm, self._user)
         return t
+
+
+class _UserHandle:
+    """Owns a mcmc_target_compile handle."""
+
+    def __init__(self, value):
+        self.value = value
+
+    def __del__(self):
+        if getattr(self, "value", None):
+            lib.mcmc_target_destroy(self.value)
+            self.value = None
 
 
 def _need_target(target) -> Target:
@@ -64,7 +103,8 @@ def _need_target(target) -> Target:
         raise TypeError(
             "target is a host callable; a GPU cannot call back into the interpreter "
             "(adaptMCMC_source.cpp:97,158). Pass a mcmc_amd.Target descriptor "
-            "(Target.gaussian / goldstein_price / banana)."
+            "(Target.gaussian / goldstein_price / banana), or the function as HIP source "
+            "through Target.compile."
         )
     raise TypeError("target must be a mcmc_amd.Target")
 
@@ -328,6 +368,18 @@ def adapt_rwm_batch(target, n_chains, init_theta, covmat, n_iterations, adapt_si
         io.d_rate_trace = _dev_ptr(buf("rate_trace", (n, n_chains)))
     ct = t._c()
     check(lib.mcmc_adapt_rwm_batch(C.byref(ct), C.byref(cfg), C.byref(io), _stream_ptr()))
+    return out
+
+
+def target_eval_batch(target, x):
+    """log-density of `target` at the columns of x ([d, n] CUDA tensor) -> [n] CUDA tensor
+    (mcmc_target_eval_batch): checks a compiled target against its host definition."""
+    torch = _torch()
+    t = _need_target(target)
+    d, n = x.shape
+    out = torch.empty((n,), dtype=torch.float64, device=x.device)
+    ct = t._c()
+    check(lib.mcmc_target_eval_batch(C.byref(ct), int(d), int(n), _dev_ptr(x, torch.float64), _dev_ptr(out), _stream_ptr()))
     return out
 
 

@@ -44,9 +44,14 @@ static int build_rwm_params(const mcmc_target *target, int d, const double *h_in
 {
     p.d = d;
     p.target_kind = target->kind;
-    const int np = target_param_count(target->kind, d);
-    if (target->kind < 0 || target->kind > MCMC_TARGET_BANANA)
+    if (target->kind < 0 || target->kind > MCMC_TARGET_USER)
         return set_error(MCMC_E_BAD_ARG, "unknown target kind %d", target->kind);
+    int np = target_param_count(target->kind, d);
+    if (target->kind == MCMC_TARGET_USER) {
+        np = user_target_param_count(target->user, d);
+        if (np < 0) return np;
+        p.user = target->user;
+    }
     if (target->n_params != np || (np > 0 && !target->h_params))
         return set_error(MCMC_E_BAD_ARG, "target kind %d with d=%d needs %d parameters, got %d", target->kind, d, np,
                          target->n_params);
@@ -145,7 +150,7 @@ extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_co
         return set_error(MCMC_E_UNSUPPORTED, "one-chain-per-lane kernel: d=%d above its limit %d", d, kMaxLaneDimRwm);
     const bool use_block = cfg->kernel == MCMC_KERNEL_BLOCK || (cfg->kernel == MCMC_KERNEL_AUTO && d > kMaxLaneDimRwm);
     if (use_block && target->kind != MCMC_TARGET_GAUSSIAN_PREC)
-        return set_error(MCMC_E_UNSUPPORTED, "the per-workgroup kernel serves the Gaussian target only");
+        return set_error(MCMC_E_UNSUPPORTED, "the per-workgroup kernel (d > %d) serves the Gaussian target only", kMaxLaneDimRwm);
 
     RwmParams p;
     int rc = build_rwm_params(target, d, io->h_init_theta, io->h_covmat, p);

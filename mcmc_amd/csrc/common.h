@@ -1,14 +1,19 @@
 // Shared host-side declarations of the engine (error handling, launch plumbing).
 #pragma once
+// Under hipRTC (user targets, rtc.hip) only the device-side declarations are seen: the run-time
+// compiler has no host headers.
 #include <hip/hip_runtime.h>
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
 
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <functional>
 #include <vector>
+#endif
 
-#include "../../include/mcmc_amd.h"
+#include "mcmc_amd.h"
 
 namespace mcmc {
 
@@ -22,6 +27,7 @@ constexpr int kMaxDimGibbs = 256;
 constexpr int kGibbsLaneMaxDim = 32;
 constexpr int kMaxDimRwm = 128;
 
+#ifndef __HIPCC_RTC__
 int set_error(int code, const char *fmt, ...);
 
 #define MCMC_HIP_CHECK(expr)                                                                       \
@@ -31,6 +37,7 @@ int set_error(int code, const char *fmt, ...);
             return ::mcmc::set_error(MCMC_E_HIP, "%s failed: %s (%s:%d)", #expr,                   \
                                      hipGetErrorString(_e), __FILE__, __LINE__);                   \
     } while (0)
+#endif
 
 // ---- arguments common to every Gibbs kernel (plain data, passed by value) -------------
 struct GibbsArgs {
@@ -50,6 +57,7 @@ struct GibbsArgs {
     int32_t *d_status;
 };
 
+#ifndef __HIPCC_RTC__
 // shared (per-call) Gibbs parameters on the host: mu, sd, lower, upper, init, P (row i has d-1 entries)
 struct GibbsParams {
     int d;
@@ -61,6 +69,7 @@ int launch_gibbs_streams(uint64_t seed, int64_t chain_offset, int64_t n_chains, 
                          int32_t d, double *d_U, hipStream_t s);
 int launch_rtnorm(int64_t n, double mu, double sigma, double a, double b, const double *d_F,
                   uint64_t seed, int64_t offset, bool tail_safe, double *d_out, hipStream_t s);
+#endif
 
 // ---- arguments common to every random-walk Metropolis kernel ---------------------------
 struct RwmArgs {
@@ -97,6 +106,7 @@ struct RwmArgs {
     double *d_rate_trace;
 };
 
+#ifndef __HIPCC_RTC__
 struct RwmParams {
     int d;
     int target_kind;
@@ -105,7 +115,14 @@ struct RwmParams {
     std::vector<double> R0_packed;  // chol(covmat), same packing
     double det0;                    // det(covmat) = prod(diag R0)^2
     std::vector<double> tparams;    // target parameter block
+    const void *user = nullptr;     // MCMC_TARGET_USER: the handle mcmc_target_compile returned
 };
+
+// How a Metropolis kernel gets onto the device: the kernels compiled into the library go through
+// hipLaunchKernelGGL, a run-time compiled user-target module through hipModuleLaunchKernel (rtc.hip).
+// `variant` is the kernel's bool template argument (FULL of the lane kernel, MOMENTS of the pair kernel).
+using RwmLauncher = std::function<hipError_t(bool variant, unsigned grid, unsigned block, size_t lds_bytes,
+                                             hipStream_t s, const RwmArgs &a, const double *d_prm)>;
 
 int launch_rwm_lane(const RwmArgs &a, const RwmParams &p, hipStream_t s);
 int launch_rwm_block(const RwmArgs &a, const RwmParams &p, hipStream_t s);
@@ -115,8 +132,59 @@ int launch_rwm_streams(uint64_t seed, int64_t chain_offset, int64_t n_chains, in
                        int32_t d, double *d_Z, double *d_U, hipStream_t s);
 int launch_init_normal(uint64_t seed, int64_t chain_offset, int64_t n_chains, int32_t d,
                        const double *h_mean, double sd, double *d_out, hipStream_t s);
+// rtc.hip: the same two launches for a MCMC_TARGET_USER target
+int launch_rwm_lane_user(const RwmArgs &a, const RwmParams &p, hipStream_t s);
+int launch_rwm_pair_user(const RwmArgs &a, const RwmParams &p, hipStream_t s);
+int user_target_param_count(const void *handle, int d);
+#endif
 
 // packed upper-triangular index, r <= c
 __host__ __device__ constexpr int tri(int r, int c) { return c * (c + 1) / 2 + r; }
+
+// ---- parameter-block / LDS layouts of the one-chain-per-lane kernels ---------------------------
+// constexpr functions of (d, number of target parameters), so that the kernels use them as
+// compile-time constants and the host can lay out the block for a run-time compiled kernel.
+//
+// lane kernel, block in HBM (doubles): init[D] cov[T] R0[T] root0 tprm[NP]; T = D(D+1)/2.
+// cov = covmat_proposal_init and R0 = chol(covmat), both packed upper: (r,c), r<=c at c(c+1)/2+r.
+struct LaneLayout {
+    int T, NP, INIT, COV, R0, ROOT0, TPRM, TOTAL;
+    int SH;          // shared parameters staged in LDS (16-B aligned size)
+    int LDS_DOUBLES; // + covmat_empirical and theta_mean as [e][lane]
+};
+__host__ __device__ constexpr LaneLayout lane_layout(int D, int NP)
+{
+    const int T = D * (D + 1) / 2, TPRM = D + 2 * T + 1, TOTAL = TPRM + NP, SH = (TOTAL + 1) & ~1;
+    return LaneLayout{T, NP, 0, D, D + T, D + 2 * T, TPRM, TOTAL, SH, SH + (T + D) * 64};
+}
+
+constexpr int kPairGroups = 4; // chain groups (of 64) per workgroup = sampler waves = generator waves
+
+// pair kernel, block in HBM (doubles): min diag(covmat), -, tprm[NP] | init[D] R0[T] prodR0
+// the first SH doubles are staged in LDS; the rest is read once (or on a rare phase change)
+struct PairLayoutRT {
+    int T, NP, COVD, TPRM, SH, INIT, R0, PROD0, TOTAL;
+    // per chain group, all as [element][lane]:
+    int DRAW;  // generator -> sampler: Y[D], exp(-q/2), log A
+    int BACK;  // sampler -> generator: theta of the iteration just finished
+    int CX;    // covmat_empirical: updated by the generator, read by the sampler when it factors
+    int GROUP; // + 8 doubles of flags
+    int LDS_DOUBLES;
+};
+__host__ __device__ constexpr PairLayoutRT pair_layout(int D, int NP, bool MOMENTS)
+{
+    const int T = D * (D + 1) / 2, SH = (2 + NP + 1) & ~1;
+    const int DRAW = D + 2, BACK = MOMENTS ? D : 0, CX = MOMENTS ? T : 0, GROUP = (DRAW + BACK + CX) * 64 + 8;
+    return PairLayoutRT{T, NP, 0, 2, SH, SH, SH + D, SH + D + T, SH + D + T + 1, DRAW, BACK, CX, GROUP, SH + kPairGroups * GROUP};
+}
+
+#ifndef __HIPCC_RTC__
+// the launches proper, shared by the built-in and the run-time compiled kernels; `packed_tparams`
+// is the target parameter block as the pair kernel wants it (PackedTarget::pack)
+int launch_rwm_lane_with(const RwmArgs &a, const RwmParams &p, hipStream_t s, const LaneLayout &L,
+                         const RwmLauncher &launch);
+int launch_rwm_pair_with(const RwmArgs &a, const RwmParams &p, hipStream_t s, int n_packed,
+                         const std::vector<double> &packed_tparams, const RwmLauncher &launch);
+#endif
 
 } // namespace mcmc

@@ -11,7 +11,9 @@
 // Results therefore do not depend on how chains are spread over lanes, launches or GPUs.
 #pragma once
 #include <hip/hip_runtime.h>
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 
 #include "fastmath.h"
 

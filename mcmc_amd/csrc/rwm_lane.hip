@@ -29,16 +29,13 @@
 
 namespace mcmc {
 
-// parameter block in HBM (doubles): init[D] cov[T] R0[T] root0 tprm[NP]; T = D(D+1)/2.
-// cov = covmat_proposal_init and R0 = chol(covmat), both packed upper: (r,c), r<=c at c(c+1)/2+r.
+// parameter block and LDS layout: lane_layout() in common.h
 template <int D, int KIND>
 struct RwmLayout {
-    static constexpr int T = D * (D + 1) / 2;
-    static constexpr int NP = target_param_count(KIND, D);
-    static constexpr int INIT = 0, COV = D, R0 = D + T, ROOT0 = D + 2 * T, TPRM = D + 2 * T + 1;
-    static constexpr int TOTAL = TPRM + NP;
-    static constexpr int SH = (TOTAL + 1) & ~1;       // shared parameters staged in LDS (16-B aligned size)
-    static constexpr int LDS_DOUBLES = SH + (T + D) * 64; // + covmat_empirical and theta_mean as [e][lane]
+    static constexpr LaneLayout L = lane_layout(D, target_param_count(KIND, D));
+    static constexpr int T = L.T, NP = L.NP;
+    static constexpr int INIT = L.INIT, COV = L.COV, R0 = L.R0, ROOT0 = L.ROOT0, TPRM = L.TPRM;
+    static constexpr int TOTAL = L.TOTAL, SH = L.SH, LDS_DOUBLES = L.LDS_DOUBLES;
 };
 
 // view of the target parameters inside the block, indexable like an array
@@ -286,6 +283,7 @@ __global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const dou
     }
 }
 
+#ifndef __HIPCC_RTC__
 // The normals / uniforms a Philox run draws: Z [n_iterations][d][n], U [n_iterations][n].
 __global__ __launch_bounds__(256) void rwm_streams_kernel(uint64_t seed, int64_t chain_offset, int64_t n,
                                                           int32_t n_iterations, int32_t d, double *Z, double *U)
@@ -327,42 +325,52 @@ __global__ __launch_bounds__(256) void init_normal_kernel(uint64_t seed, int64_t
 }
 
 // ------------------------------------------------------------------------------------------
-template <int D, int KIND>
-static int launch_rwm_lane_dk(const RwmArgs &a, const RwmParams &p, hipStream_t s)
+int launch_rwm_lane_with(const RwmArgs &a, const RwmParams &p, hipStream_t s, const LaneLayout &L, const RwmLauncher &launch)
 {
-    using Lay = RwmLayout<D, KIND>;
-    if ((int)p.tparams.size() != Lay::NP)
-        return set_error(MCMC_E_BAD_ARG, "target kind %d with d=%d needs %d parameters, got %d", KIND, D, Lay::NP,
+    const int D = a.d;
+    if ((int)p.tparams.size() != L.NP)
+        return set_error(MCMC_E_BAD_ARG, "target kind %d with d=%d needs %d parameters, got %d", p.target_kind, D, L.NP,
                          (int)p.tparams.size());
-    std::vector<double> blob(Lay::TOTAL, 0.0);
-    for (int k = 0; k < D; ++k) blob[Lay::INIT + k] = p.init[k];
-    for (int e = 0; e < Lay::T; ++e) {
-        blob[Lay::COV + e] = p.cov_packed[e];
-        blob[Lay::R0 + e] = p.R0_packed[e];
+    std::vector<double> blob(L.TOTAL, 0.0);
+    for (int k = 0; k < D; ++k) blob[L.INIT + k] = p.init[k];
+    for (int e = 0; e < L.T; ++e) {
+        blob[L.COV + e] = p.cov_packed[e];
+        blob[L.R0 + e] = p.R0_packed[e];
     }
-    blob[Lay::ROOT0] = 1.0 / std::sqrt(a.twopi_pow_d * p.det0);
-    for (int e = 0; e < Lay::NP; ++e) blob[Lay::TPRM + e] = p.tparams[e];
+    blob[L.ROOT0] = 1.0 / std::sqrt(a.twopi_pow_d * p.det0);
+    for (int e = 0; e < L.NP; ++e) blob[L.TPRM + e] = p.tparams[e];
     double *d_prm = nullptr;
     MCMC_HIP_CHECK(hipMallocAsync((void **)&d_prm, blob.size() * sizeof(double), s));
     MCMC_HIP_CHECK(hipMemcpyAsync(d_prm, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, s));
     MCMC_HIP_CHECK(hipStreamSynchronize(s)); // blob is a local: do not let the copy outlive it
     const int64_t grid = (a.n_chains + 63) / 64;
-    const size_t ldsb = (size_t)Lay::LDS_DOUBLES * sizeof(double);
+    const size_t ldsb = (size_t)L.LDS_DOUBLES * sizeof(double);
     const bool full = a.d_Z || a.d_sigma_trace || a.d_accepted || a.d_log_acceptance || a.d_log_A || a.d_scaling_sd ||
                       a.d_scaling_multiplier || a.d_rate_trace;
-    if (full)
-        hipLaunchKernelGGL((rwm_lane_kernel<D, KIND, true>), dim3((unsigned)grid), dim3(64), ldsb, s, a, (const double *)d_prm);
-    else
-        hipLaunchKernelGGL((rwm_lane_kernel<D, KIND, false>), dim3((unsigned)grid), dim3(64), ldsb, s, a, (const double *)d_prm);
-    hipError_t e1 = hipGetLastError();
+    hipError_t e1 = launch(full, (unsigned)grid, 64u, ldsb, s, a, d_prm);
     hipError_t e2 = hipFreeAsync(d_prm, s);
     if (e1 != hipSuccess) return set_error(MCMC_E_HIP, "rwm_lane_kernel launch failed: %s", hipGetErrorString(e1));
     if (e2 != hipSuccess) return set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e2));
     return MCMC_OK;
 }
 
+template <int D, int KIND>
+static int launch_rwm_lane_dk(const RwmArgs &a, const RwmParams &p, hipStream_t s)
+{
+    return launch_rwm_lane_with(a, p, s, RwmLayout<D, KIND>::L,
+                                [](bool full, unsigned grid, unsigned block, size_t ldsb, hipStream_t st, const RwmArgs &aa,
+                                   const double *d_prm) {
+                                    if (full)
+                                        hipLaunchKernelGGL((rwm_lane_kernel<D, KIND, true>), dim3(grid), dim3(block), ldsb, st, aa, d_prm);
+                                    else
+                                        hipLaunchKernelGGL((rwm_lane_kernel<D, KIND, false>), dim3(grid), dim3(block), ldsb, st, aa, d_prm);
+                                    return hipGetLastError();
+                                });
+}
+
 int launch_rwm_lane(const RwmArgs &a, const RwmParams &p, hipStream_t s)
 {
+    if (p.target_kind == MCMC_TARGET_USER) return launch_rwm_lane_user(a, p, s);
     if (p.target_kind == MCMC_TARGET_GOLDSTEIN_PRICE) {
         if (a.d != 2) return set_error(MCMC_E_BAD_ARG, "Goldstein-Price target is 2-dimensional (d=%d)", a.d);
         return launch_rwm_lane_dk<2, MCMC_TARGET_GOLDSTEIN_PRICE>(a, p, s);
@@ -409,5 +417,7 @@ int launch_init_normal(uint64_t seed, int64_t chain_offset, int64_t n_chains, in
     MCMC_HIP_CHECK(hipFreeAsync(d_mean, s));
     return MCMC_OK;
 }
+
+#endif // !__HIPCC_RTC__
 
 } // namespace mcmc

@@ -51,6 +51,7 @@ struct PackedTarget;
 template <int D>
 struct PackedTarget<MCMC_TARGET_GAUSSIAN_PREC, D> {
     static constexpr int NP = 2 * D + D * (D - 1) / 2;
+#ifndef __HIPCC_RTC__
     static void pack(const std::vector<double> &tp, double *out)
     {
         for (int k = 0; k < D; ++k) out[k] = tp[k];
@@ -60,6 +61,7 @@ struct PackedTarget<MCMC_TARGET_GAUSSIAN_PREC, D> {
             for (int i = 0; i < j; ++i) out[2 * D + j * (j - 1) / 2 + i] = H[j * D + i] + H[i * D + j];
         }
     }
+#endif
     // The sampler keeps the chain state CENTRED, v = theta - m (one subtraction at the start, one addition
     // per stored value), so the target reads the state as it is: -0.5 sum_j v_j (H_jj v_j + sum_{i<j} (H_ij + H_ji) v_i)
     static constexpr bool CENTRED = true;
@@ -86,7 +88,9 @@ template <>
 struct PackedTarget<MCMC_TARGET_GOLDSTEIN_PRICE, 2> {
     static constexpr int NP = 0;
     static constexpr bool CENTRED = false;
+#ifndef __HIPCC_RTC__
     static void pack(const std::vector<double> &, double *) {}
+#endif
     __device__ static __forceinline__ double eval(const double (&x)[2], const double *p)
     {
         return Target<MCMC_TARGET_GOLDSTEIN_PRICE, 2>::eval(x, PackedPrmView{p});
@@ -97,31 +101,35 @@ template <>
 struct PackedTarget<MCMC_TARGET_BANANA, 2> {
     static constexpr int NP = 1;
     static constexpr bool CENTRED = false;
+#ifndef __HIPCC_RTC__
     static void pack(const std::vector<double> &tp, double *out) { out[0] = tp[0]; }
+#endif
     __device__ static __forceinline__ double eval(const double (&x)[2], const double *p)
     {
         return Target<MCMC_TARGET_BANANA, 2>::eval(x, PackedPrmView{p});
     }
 };
 
-constexpr int kPairGroups = 4; // chain groups (of 64) per workgroup = sampler waves = generator waves
+#ifdef MCMC_USER_D
+// a run-time compiled user target reads its parameters as the caller gave them
+template <>
+struct PackedTarget<MCMC_TARGET_USER, MCMC_USER_D> {
+    static constexpr int NP = MCMC_USER_NP;
+    static constexpr bool CENTRED = false;
+    __device__ static __forceinline__ double eval(const double (&x)[MCMC_USER_D], const double *p)
+    {
+        return ::mcmc_user_target(x, p);
+    }
+};
+#endif
 
-// parameter block in HBM (doubles): min diag(covmat), tprm[NP] | init[D] R0[T] prodR0
-// the first SH doubles are staged in LDS; the rest is read once (or on a rare phase change)
+// parameter block and LDS layout: pair_layout() in common.h
 template <int D, int KIND, bool MOMENTS>
 struct PairLayout {
-    static constexpr int T = D * (D + 1) / 2;
-    static constexpr int NP = PackedTarget<KIND, D>::NP;
-    static constexpr int COVD = 0, TPRM = 2;
-    static constexpr int SH = (2 + NP + 1) & ~1;
-    static constexpr int INIT = SH, R0 = SH + D, PROD0 = SH + D + T;
-    static constexpr int TOTAL = PROD0 + 1;
-    // per chain group, all as [element][lane]:
-    static constexpr int DRAW = D + 2;              // generator -> sampler: Y[D], exp(-q/2), log A
-    static constexpr int BACK = MOMENTS ? D : 0;    // sampler -> generator: theta of the iteration just finished
-    static constexpr int CX = MOMENTS ? T : 0;      // covmat_empirical: updated by the generator, read by the sampler when it factors
-    static constexpr int GROUP = (DRAW + BACK + CX) * 64 + 8; // + 8 doubles of flags
-    static constexpr int LDS_DOUBLES = SH + kPairGroups * GROUP;
+    static constexpr PairLayoutRT L = pair_layout(D, PackedTarget<KIND, D>::NP, MOMENTS);
+    static constexpr int T = L.T, NP = L.NP;
+    static constexpr int COVD = L.COVD, TPRM = L.TPRM, SH = L.SH, INIT = L.INIT, R0 = L.R0, PROD0 = L.PROD0, TOTAL = L.TOTAL;
+    static constexpr int DRAW = L.DRAW, BACK = L.BACK, CX = L.CX, GROUP = L.GROUP, LDS_DOUBLES = L.LDS_DOUBLES;
 };
 
 // a value that is the same in every lane, moved to a scalar register pair
@@ -490,49 +498,58 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
     }
 }
 
+#ifndef __HIPCC_RTC__
 // ------------------------------------------------------------------------------------------
-template <int D, int KIND>
-static int launch_rwm_pair_dk(const RwmArgs &a, const RwmParams &p, hipStream_t s)
+int launch_rwm_pair_with(const RwmArgs &a, const RwmParams &p, hipStream_t s, int n_packed,
+                         const std::vector<double> &packed_tparams, const RwmLauncher &launch)
 {
-    using Lay = PairLayout<D, KIND, true>;
-    if ((int)p.tparams.size() != target_param_count(KIND, D))
-        return set_error(MCMC_E_BAD_ARG, "target kind %d with d=%d needs %d parameters, got %d", KIND, D,
-                         target_param_count(KIND, D), (int)p.tparams.size());
-    std::vector<double> blob(Lay::TOTAL, 0.0);
+    const int D = a.d;
+    const bool moments = a.adapt_shape_start != 0 || a.d_final_mean || a.d_final_cov;
+    const PairLayoutRT L = pair_layout(D, n_packed, moments); // the HBM block does not depend on `moments`
+    if ((int)packed_tparams.size() != n_packed) return set_error(MCMC_E_BAD_ARG, "pair kernel: target parameter block of the wrong size");
+    std::vector<double> blob(L.TOTAL, 0.0);
     double prod0 = 1.0;
     double min_var = p.cov_packed[0];
     for (int k = 0; k < D; ++k) {
         min_var = std::fmin(min_var, p.cov_packed[tri(k, k)]);
-        blob[Lay::INIT + k] = p.init[k];
+        blob[L.INIT + k] = p.init[k];
         prod0 *= p.R0_packed[tri(k, k)];
     }
-    blob[Lay::COVD] = min_var;
-    PackedTarget<KIND, D>::pack(p.tparams, blob.data() + Lay::TPRM);
-    for (int e = 0; e < Lay::T; ++e) blob[Lay::R0 + e] = p.R0_packed[e];
-    blob[Lay::PROD0] = prod0;
+    blob[L.COVD] = min_var;
+    for (int e = 0; e < n_packed; ++e) blob[L.TPRM + e] = packed_tparams[e];
+    for (int e = 0; e < L.T; ++e) blob[L.R0 + e] = p.R0_packed[e];
+    blob[L.PROD0] = prod0;
     double *d_prm = nullptr;
     MCMC_HIP_CHECK(hipMallocAsync((void **)&d_prm, blob.size() * sizeof(double), s));
     MCMC_HIP_CHECK(hipMemcpyAsync(d_prm, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, s));
     MCMC_HIP_CHECK(hipStreamSynchronize(s)); // blob is a local: do not let the copy outlive it
     const int64_t grid = (a.n_chains + 64 * kPairGroups - 1) / (64 * kPairGroups);
-    const bool moments = a.adapt_shape_start != 0 || a.d_final_mean || a.d_final_cov;
-    hipError_t e0 = hipSuccess;
-    auto go = [&](auto kern, size_t lds_doubles) {
-        const size_t ldsb = lds_doubles * sizeof(double);
-        e0 = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-        if (e0 == hipSuccess)
-            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(128 * kPairGroups), ldsb, s, a, (const double *)d_prm);
-    };
-    if (moments)
-        go(rwm_pair_kernel<D, KIND, true>, PairLayout<D, KIND, true>::LDS_DOUBLES);
-    else
-        go(rwm_pair_kernel<D, KIND, false>, PairLayout<D, KIND, false>::LDS_DOUBLES);
-    hipError_t e1 = hipGetLastError();
+    hipError_t e1 = launch(moments, (unsigned)grid, 128u * kPairGroups, (size_t)L.LDS_DOUBLES * sizeof(double), s, a, d_prm);
     hipError_t e2 = hipFreeAsync(d_prm, s);
-    if (e0 != hipSuccess) return set_error(MCMC_E_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e0));
     if (e1 != hipSuccess) return set_error(MCMC_E_HIP, "rwm_pair_kernel launch failed: %s", hipGetErrorString(e1));
     if (e2 != hipSuccess) return set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e2));
     return MCMC_OK;
+}
+
+template <int D, int KIND>
+static int launch_rwm_pair_dk(const RwmArgs &a, const RwmParams &p, hipStream_t s)
+{
+    if ((int)p.tparams.size() != target_param_count(KIND, D))
+        return set_error(MCMC_E_BAD_ARG, "target kind %d with d=%d needs %d parameters, got %d", KIND, D,
+                         target_param_count(KIND, D), (int)p.tparams.size());
+    std::vector<double> packed(PackedTarget<KIND, D>::NP, 0.0);
+    PackedTarget<KIND, D>::pack(p.tparams, packed.data());
+    return launch_rwm_pair_with(
+        a, p, s, PackedTarget<KIND, D>::NP, packed,
+        [](bool moments, unsigned grid, unsigned block, size_t ldsb, hipStream_t st, const RwmArgs &aa, const double *d_prm) {
+            auto go = [&](auto kern) {
+                hipError_t e0 = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+                if (e0 != hipSuccess) return e0;
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(block), ldsb, st, aa, d_prm);
+                return hipGetLastError();
+            };
+            return moments ? go(rwm_pair_kernel<D, KIND, true>) : go(rwm_pair_kernel<D, KIND, false>);
+        });
 }
 
 bool rwm_pair_serves(const RwmArgs &a)
@@ -547,6 +564,7 @@ int launch_rwm_pair(const RwmArgs &a, const RwmParams &p, hipStream_t s)
     if (!rwm_pair_serves(a))
         return set_error(MCMC_E_UNSUPPORTED, "paired-wave kernel: Philox streams, no per-iteration diagnostics, d <= %d",
                          kMaxPairDimRwm);
+    if (p.target_kind == MCMC_TARGET_USER) return launch_rwm_pair_user(a, p, s);
     if (p.target_kind == MCMC_TARGET_GOLDSTEIN_PRICE) {
         if (a.d != 2) return set_error(MCMC_E_BAD_ARG, "Goldstein-Price target is 2-dimensional (d=%d)", a.d);
         return launch_rwm_pair_dk<2, MCMC_TARGET_GOLDSTEIN_PRICE>(a, p, s);
@@ -566,5 +584,7 @@ int launch_rwm_pair(const RwmArgs &a, const RwmParams &p, hipStream_t s)
     default: return set_error(MCMC_E_UNSUPPORTED, "paired-wave kernel: d=%d outside 1..%d", a.d, kMaxPairDimRwm);
     }
 }
+
+#endif // !__HIPCC_RTC__
 
 } // namespace mcmc

@@ -3,15 +3,24 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "../../include/mcmc_amd.h"
+#include "mcmc_amd.h"
 #include "fastmath.h"
+
+// A user target exists only inside a run-time compiled module (rtc.hip defines MCMC_USER_D and
+// MCMC_USER_NP ahead of the kernel sources and appends the user's definition of this function).
+#ifdef MCMC_USER_D
+__device__ double mcmc_user_target(const double (&x)[MCMC_USER_D], const double *params);
+#else
+#define MCMC_USER_NP 0
+#endif
 
 namespace mcmc {
 
 // parameter block sizes (doubles) per kind, for a given d
 __host__ __device__ constexpr int target_param_count(int kind, int d)
 {
-    return kind == MCMC_TARGET_GAUSSIAN_PREC ? d + d * d : (kind == MCMC_TARGET_BANANA ? 1 : 0);
+    return kind == MCMC_TARGET_GAUSSIAN_PREC ? d + d * d
+                                             : (kind == MCMC_TARGET_BANANA ? 1 : (kind == MCMC_TARGET_USER ? MCMC_USER_NP : 0));
 }
 
 template <int KIND, int D>
@@ -69,5 +78,34 @@ struct Target<MCMC_TARGET_BANANA, 2> {
         return -(x[0] * x[0]) / 200 - 1.0 / 2 * (u * u);
     }
 };
+
+#ifdef MCMC_USER_D
+// prm is a view of the parameter block in LDS (PrmView / PackedPrmView: a pointer named p)
+template <>
+struct Target<MCMC_TARGET_USER, MCMC_USER_D> {
+    template <class Prm>
+    __device__ static inline double eval(const double (&x)[MCMC_USER_D], const Prm &prm)
+    {
+        return ::mcmc_user_target(x, prm.p);
+    }
+};
+#endif
+
+// log-density at n points, x as [D][n]: mcmc_target_eval_batch
+template <int D, int KIND>
+__global__ __launch_bounds__(256) void target_eval_kernel(int64_t n, const double *__restrict__ x,
+                                                          const double *__restrict__ prm, double *__restrict__ out)
+{
+    struct View {
+        const double *p;
+        __device__ double operator[](int i) const { return p[i]; }
+    };
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    double v[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) v[k] = x[(int64_t)k * n + c];
+    out[c] = Target<KIND, D>::eval(v, View{prm});
+}
 
 } // namespace mcmc

@@ -164,3 +164,27 @@ def test_melt_trace_matches_the_reference_layout():
     np.testing.assert_array_equal(sub[0]["trace"], tr[:, :, 3])
     with pytest.raises(ValueError):
         mcmc_amd.melt_trace([])
+
+
+def test_user_target_compiles_without_a_gpu_and_reports_diagnostics():
+    """mcmc_target_compile: hipRTC cross-compiles for gfx950 with no device."""
+    import mcmc_amd
+
+    src = """
+__device__ double mcmc_user_target(const double (&x)[MCMC_USER_D], const double *params)
+{
+    double s = 0.0;
+    for (int k = 0; k < MCMC_USER_D; ++k) s += params[0] * x[k] * x[k];
+    return -0.5 * s;
+}
+"""
+    t = mcmc_amd.Target.compile(src, 3, [2.0])
+    assert t.kind == 3 and t._user.value
+    c = t._c()
+    assert c.kind == 3 and c.n_params == 1 and c.user == t._user.value
+    with pytest.raises(mcmc_amd.McmcError, match="undeclared identifier 'y'"):
+        mcmc_amd.Target.compile("__device__ double mcmc_user_target(const double (&x)[MCMC_USER_D], const double *p) { return y; }", 2)
+    with pytest.raises(mcmc_amd.McmcError, match="outside 1..12"):
+        mcmc_amd.Target.compile(src, 13, [2.0])
+    with pytest.raises(ValueError):
+        t.with_params([1.0, 2.0])

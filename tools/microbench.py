@@ -109,3 +109,47 @@ if __name__ == "__main__" and "shape" in sys.argv:
     rwm_block_shape(100, 3072, 1000)
     rwm_block_shape(64, 3072, 1000)
     rwm_block_shape(32, 6144, 1000)
+
+
+GAUSS_USER_SRC = r"""
+// -0.5 (x-m)^T H (x-m) written the obvious way: params = m[d], H[d*d] column-major
+__device__ double mcmc_user_target(const double (&x)[MCMC_USER_D], const double *params)
+{
+    constexpr int D = MCMC_USER_D;
+    double v[D], q = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) v[k] = x[k] - params[k];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) s += params[D + j * D + i] * v[j];
+        q += v[i] * s;
+    }
+    return -0.5 * q;
+}
+"""
+
+
+def rwm_user(d, chains, iters):
+    """C2 shape with the Gaussian target built in vs the same density compiled at run time as a user target"""
+    idx = np.arange(d)
+    Sig = 0.9 ** np.abs(idx[:, None] - idx[None, :])
+    H = np.linalg.inv(Sig); H = 0.5 * (H + H.T)
+    import time
+    t0 = time.perf_counter()
+    user = mcmc_amd.Target.compile(GAUSS_USER_SRC, d, np.concatenate([np.zeros(d), H.ravel(order="F")]))
+    t_compile = time.perf_counter() - t0
+    init = mcmc_amd.init_normal(1, chains, np.zeros(d), 2.0)
+    out = {}
+    for name, tgt in (("built-in", mcmc_amd.Target.gaussian(np.zeros(d), H)), ("user (hipRTC)", user)):
+        f = lambda: out.update(mcmc_amd.adapt_rwm_batch(tgt, chains, init, np.eye(d), iters, 100, 0.0, 0, 500, seed=1, final=False,
+                                                        out=out))
+        ms = timeit(f, reps=3)
+        print(f"rwm d={d} chains={chains} iters={iters} target {name}: {ms:.2f} ms  {chains*iters/(ms*1e-3):.3e} chain-iter/s"
+              + (f"  (compile {t_compile:.1f} s)" if tgt is user else ""))
+
+
+if __name__ == "__main__" and "user" in sys.argv:
+    rwm_user(10, 1 << 16, 2000)
+    rwm_user(4, 1 << 18, 1000)
