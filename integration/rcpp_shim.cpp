@@ -8,9 +8,11 @@
 //
 // `target` is either a list describing a device target
 //     list(kind = "gaussian", mean = m, precision = H) | list(kind = "goldstein_price") |
-//     list(kind = "banana", B = 0.03)
+//     list(kind = "banana", B = 0.03) |
+//     list(kind = "hip", source = "<HIP device source of mcmc_user_target>", params = c(...))
 // or an R function.  A GPU cannot call an R closure (adaptMCMC_source.cpp:97,158), so functions are
-// refused here with a message; keep sourcing the reference's own adaptMCMC_source.cpp for those.
+// refused here with a message: restate the closure as HIP source (kind = "hip", compiled once per
+// call by mcmc_target_compile, ~1-3 s) or keep sourcing the reference's own adaptMCMC_source.cpp.
 #include <RcppArmadillo.h>
 // [[Rcpp::depends(RcppArmadillo)]]
 #include "mcmc_amd.h"
@@ -18,13 +20,22 @@ using namespace Rcpp;
 
 namespace {
 struct TargetDesc {
-    mcmc_target t;
+    mcmc_target t{};
     std::vector<double> prm;
+    void *user = nullptr;
+    TargetDesc() = default;
+    TargetDesc(const TargetDesc &) = delete;
+    TargetDesc(TargetDesc &&o) : t(o.t), prm(std::move(o.prm)), user(o.user) { o.user = nullptr; }
+    ~TargetDesc()
+    {
+        if (user) mcmc_target_destroy(user);
+    }
 };
 TargetDesc make_target(SEXP target, int d)
 {
     if (Rf_isFunction(target))
-        stop("mcmc_amd: `target` is an R function; pass list(kind=...) for the GPU path or use the reference sampler");
+        stop("mcmc_amd: `target` is an R function; pass list(kind=...) (kind = \"hip\" takes the function as HIP source) "
+             "for the GPU path or use the reference sampler");
     List l(target);
     std::string kind = as<std::string>(l["kind"]);
     TargetDesc out;
@@ -39,10 +50,17 @@ TargetDesc make_target(SEXP target, int d)
     } else if (kind == "banana") {
         out.prm.push_back(l.containsElementNamed("B") ? as<double>(l["B"]) : 0.03);
         out.t.kind = MCMC_TARGET_BANANA;
+    } else if (kind == "hip") {
+        std::string src = as<std::string>(l["source"]);
+        if (l.containsElementNamed("params")) out.prm = as<std::vector<double>>(l["params"]);
+        std::vector<char> log(1 << 16);
+        if (mcmc_target_compile(src.c_str(), d, (int)out.prm.size(), &out.user, log.data(), (int64_t)log.size()) != MCMC_OK)
+            stop("mcmc_amd: %s\n%s", mcmc_amd_last_error(), log.data());
+        out.t.kind = MCMC_TARGET_USER;
+        out.t.user = out.user;
     } else {
         stop("mcmc_amd: unknown target kind '%s'", kind);
     }
-    (void)d;
     out.t.n_params = (int)out.prm.size();
     out.t.h_params = out.prm.empty() ? nullptr : out.prm.data();
     return out;
