@@ -52,6 +52,7 @@ extern "C" {
 #define MCMC_CHAIN_CHOL_FAILED 1      /* arma::chol would have thrown (adaptMCMC_source.cpp:153) */
 #define MCMC_CHAIN_NONFINITE_STATE 2  /* Gibbs draw became +-Inf/NaN (tmvrnormGibbs.cpp:132 has no tail handling) */
 #define MCMC_CHAIN_SYNC_LOST 3        /* internal hand-shake between the wavefronts of a chain group timed out (a bug, never data) */
+#define MCMC_CHAIN_BAD_STATE 4        /* resume: d_state_in was not written by this kernel at iteration iter_offset */
 #define MCMC_STATUS_CODE(s) ((s) & 15)
 #define MCMC_STATUS_ITER(s) ((s) >> 4)
 
@@ -143,6 +144,8 @@ typedef struct mcmc_rwm_config {
     uint64_t seed;                 /* Philox key                                             */
     int32_t rng_mode;              /* MCMC_RNG_PHILOX | MCMC_RNG_INJECTED                     */
     int32_t kernel;                /* MCMC_KERNEL_AUTO (0) | _LANE | _BLOCK | _PAIR: which device kernel runs */
+    int32_t iter_offset;           /* resume: iterations already done (0 = fresh start). This call runs iterations
+                                      iter_offset+1 .. iter_offset+n_iterations and needs io->d_state_in         */
 } mcmc_rwm_config;
 
 typedef struct mcmc_rwm_io {
@@ -168,11 +171,34 @@ typedef struct mcmc_rwm_io {
     double *d_scaling_multiplier;  /* scaling_multiplier after the adaptation block (:123)    */
     double *d_rate_trace;          /* acceptance_rate after :188-207                          */
     /* summary, may be NULL */
-    int32_t *d_shape_iterations;   /* [n_chains] iterations whose proposal used scaling_sd^2 covmat_empirical (:131-139) */
+    int32_t *d_shape_iterations;   /* [n_chains] iterations whose proposal used scaling_sd^2 covmat_empirical (:131-139);
+                                      counted from iteration 1, across resumed launches                   */
+    /* checkpoint / resume, each may be NULL: [mcmc_rwm_state_doubles(d)][n_chains] */
+    const double *d_state_in;      /* chain state a previous call wrote (needs cfg->iter_offset = its end)  */
+    double *d_state_out;           /* chain state after the last iteration of this call                     */
 } mcmc_rwm_io;
 
 int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_config *cfg,
                          const mcmc_rwm_io *io, void *stream);
+
+/*
+ * Checkpoint / resume of chain state (no counterpart in the reference: its loop state lives in
+ * local variables and is lost on return or interrupt, adaptMCMC_source.cpp:84-105,111-114).
+ * d_state_out receives, per chain, everything the loop carries from one iteration to the next:
+ * theta_current, theta_mean, covmat_empirical and the proposal factor (packed upper triangles),
+ * target(theta_current), acceptance_rate and the acceptance window, scaling_sd, the proposal
+ * scale / determinant term, the status word and the iteration count.  A later call with the
+ * same target, covmat, adaptation parameters, seed, chain_offset, thin and kernel, with
+ * iter_offset = iterations done and d_state_in = that array, continues the run: its trace rows,
+ * rates and final state are bit-identical to those of one uninterrupted call (Philox counters
+ * are absolute iteration numbers; injected streams d_Z / d_U, the diagnostics arrays and d_trace
+ * hold this call's iterations only; a trace row is kept when the ABSOLUTE iteration is a
+ * multiple of thin, so this call writes (iter_offset+n_iterations)/thin - iter_offset/thin rows).
+ * The state is in the writing kernel's own representation and carries its tag: a state resumed by
+ * another kernel, or at another iter_offset, stops every chain with MCMC_CHAIN_BAD_STATE.
+ * The array is plain doubles: copy it to the host and write it to disk to survive the process.
+ */
+int64_t mcmc_rwm_state_doubles(int32_t d);
 
 /* Fills the N(0,1) / U(0,1) arrays that mcmc_adapt_rwm_batch would draw in MCMC_RNG_PHILOX
  * mode for the same (seed, chain_offset, n_chains, n_iterations, d), in the d_Z / d_U layout
@@ -234,6 +260,10 @@ typedef struct mcmc_gibbs_config {
                                       1 = same draw computed from whichever tail keeps
                                           precision (needed when a bound is > ~8 sd out,
                                           where the reference returns +-Inf)                  */
+    int32_t sweep_offset;          /* resume: sweeps already done (0 = fresh start).  The chain state of the
+                                      Gibbs sampler is x alone: pass the previous call's d_final_state as d_init;
+                                      Philox counters and thinning continue from sweep_offset + 1, the running
+                                      moments (d_mean, d_m2, burn) cover this call's sweeps only              */
 } mcmc_gibbs_config;
 
 typedef struct mcmc_gibbs_io {

@@ -5,10 +5,10 @@ this package is its host-side mirror of the reference interface.  Importing it l
 library and raises if it is missing: there is no CPU fallback.
 """
 from ._lib import (  # noqa: F401
-    MCMC_CHAIN_CHOL_FAILED, MCMC_CHAIN_NONFINITE_STATE, MCMC_CHAIN_OK, McmcError, lib,
+    MCMC_CHAIN_BAD_STATE, MCMC_CHAIN_CHOL_FAILED, MCMC_CHAIN_NONFINITE_STATE, MCMC_CHAIN_OK, McmcError, lib,
 )
 from .api import (  # noqa: F401
-    Target, adaptMCMC, adapt_rwm_batch, gibbs_streams, init_normal, negSubCol, negSubRow, rtmvnorm_gibbs,
+    RwmState, Target, adaptMCMC, adapt_rwm_batch, gibbs_streams, init_normal, negSubCol, negSubRow, rtmvnorm_gibbs,
     rtnorm_batch, rtnorm_gibbs, rwMCMC, rwm_streams, sub1, sub2, target_eval_batch, tmvn_gibbs_batch, tmvn_precompute,
 )
 from .chains import chain_list, melt_trace, run_chains  # noqa: F401,E402

@@ -21,6 +21,7 @@ MCMC_CHAIN_OK = 0
 MCMC_CHAIN_CHOL_FAILED = 1
 MCMC_CHAIN_NONFINITE_STATE = 2
 MCMC_CHAIN_SYNC_LOST = 3
+MCMC_CHAIN_BAD_STATE = 4
 
 MCMC_RNG_PHILOX = 0
 MCMC_RNG_INJECTED = 1
@@ -52,7 +53,7 @@ class RwmConfig(C.Structure):
         ("acceptance_window", C.c_int32), ("thin", C.c_int32),
         ("acceptance_rate_weight", C.c_double), ("adapt_size_cooling", C.c_double),
         ("max_scaling_sd", C.c_double),
-        ("seed", C.c_uint64), ("rng_mode", C.c_int32), ("kernel", C.c_int32),
+        ("seed", C.c_uint64), ("rng_mode", C.c_int32), ("kernel", C.c_int32), ("iter_offset", C.c_int32),
     ]
 
 
@@ -63,6 +64,7 @@ class RwmIO(C.Structure):
         ("d_final_cov", vp), ("d_acceptance_rate", vp), ("d_status", vp),
         ("d_accepted", vp), ("d_log_acceptance", vp), ("d_log_A", vp), ("d_scaling_sd", vp),
         ("d_scaling_multiplier", vp), ("d_rate_trace", vp), ("d_shape_iterations", vp),
+        ("d_state_in", vp), ("d_state_out", vp),
     ]
 
 
@@ -71,7 +73,7 @@ class GibbsConfig(C.Structure):
         ("d", C.c_int32), ("n_sweeps", C.c_int32),
         ("n_chains", C.c_int64), ("chain_offset", C.c_int64),
         ("thin", C.c_int32), ("burn", C.c_int32),
-        ("seed", C.c_uint64), ("rng_mode", C.c_int32), ("tail_safe", C.c_int32),
+        ("seed", C.c_uint64), ("rng_mode", C.c_int32), ("tail_safe", C.c_int32), ("sweep_offset", C.c_int32),
     ]
 
 
@@ -93,6 +95,7 @@ SIGNATURES = {
     "mcmc_target_destroy": (C.c_int, [vp]),
     "mcmc_target_eval_batch": (C.c_int, [C.POINTER(McmcTarget), C.c_int32, C.c_int64, vp, vp, vp]),
     "mcmc_adapt_rwm_batch": (C.c_int, [C.POINTER(McmcTarget), C.POINTER(RwmConfig), C.POINTER(RwmIO), vp]),
+    "mcmc_rwm_state_doubles": (C.c_int64, [C.c_int32]),
     "mcmc_rwm_streams": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, vp, vp]),
     "mcmc_init_normal": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, C.c_int32, dp, C.c_double, vp, vp]),
     "mcmc_adaptMCMC": (C.c_int, [C.POINTER(McmcTarget), C.c_int32, dp, dp, C.c_int32, C.c_int32, C.c_double,

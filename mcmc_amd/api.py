@@ -290,7 +290,7 @@ def adapt_rwm_batch(target, n_chains, init_theta, covmat, n_iterations, adapt_si
                     acceptance_rate_weight=0.0, acceptance_window=0, adapt_shape_start=0, *, seed=0,
                     adapt_size_cooling=0.99, max_scaling_sd=50.0, thin=1, chain_offset=0, Z=None, U=None,
                     trace=True, sigma_trace=False, final=True, diagnostics=False, out=None, device="cuda",
-                    kernel="auto"):
+                    kernel="auto", checkpoint=False, resume=None):
     """Many independent adaptMCMC chains in one launch (adaptMCMC_source.cpp:75-219 per chain).
 
     init_theta: length-d vector shared by all chains, or a [d, n_chains] CUDA tensor.
@@ -303,6 +303,11 @@ def adapt_rwm_batch(target, n_chains, init_theta, covmat, n_iterations, adapt_si
     `out` may carry preallocated tensors under the same keys.  kernel = "auto" | "lane" | "pair" |
     "block" picks the device kernel (auto: per lane for d <= 12 -- the paired-wave variant for Philox runs
     without diagnostics at d <= 10 -- and per 256-thread workgroup above).
+
+    checkpoint=True adds out["state"] = RwmState(array [state_doubles, n_chains], iterations done);
+    resume=<that RwmState> continues the run at its next iteration with the same arguments (bit-identical
+    to one uninterrupted call; trace rows are kept at absolute multiples of `thin`).  RwmState.save / .load
+    move it through a .npz file.
     """
     torch = _torch()
     t = _need_target(target)
@@ -320,7 +325,12 @@ def adapt_rwm_batch(target, n_chains, init_theta, covmat, n_iterations, adapt_si
         d = h_init.size
         d_init = None
     cov = _colmajor(covmat, d)
-    n_kept = n // int(thin)
+    i0 = 0
+    if resume is not None:
+        i0 = int(resume.iterations)
+        if tuple(resume.array.shape) != (int(lib.mcmc_rwm_state_doubles(d)), n_chains):
+            raise ValueError("resume state has the wrong shape for this d / n_chains")
+    n_kept = (i0 + n) // int(thin) - i0 // int(thin)
 
     def buf(key, shape, dtype=f64, want=True):
         if not want:
@@ -339,7 +349,8 @@ def adapt_rwm_batch(target, n_chains, init_theta, covmat, n_iterations, adapt_si
                       seed=int(seed) & 0xFFFFFFFFFFFFFFFF,
                       rng_mode=L.MCMC_RNG_INJECTED if Z is not None else L.MCMC_RNG_PHILOX,
                       kernel={"auto": L.MCMC_KERNEL_AUTO, "lane": L.MCMC_KERNEL_LANE, "block": L.MCMC_KERNEL_BLOCK,
-                              "pair": L.MCMC_KERNEL_PAIR}[kernel])
+                              "pair": L.MCMC_KERNEL_PAIR}[kernel],
+                      iter_offset=i0)
     if (Z is None) != (U is None):
         raise ValueError("give both Z and U, or neither")
     if Z is not None:
@@ -366,9 +377,33 @@ def adapt_rwm_batch(target, n_chains, init_theta, covmat, n_iterations, adapt_si
         io.d_scaling_sd = _dev_ptr(buf("scaling_sd", (n, n_chains)))
         io.d_scaling_multiplier = _dev_ptr(buf("scaling_multiplier", (n, n_chains)))
         io.d_rate_trace = _dev_ptr(buf("rate_trace", (n, n_chains)))
+    if resume is not None:
+        io.d_state_in = _dev_ptr(resume.array, f64)
+    if checkpoint:
+        state = torch.empty((int(lib.mcmc_rwm_state_doubles(d)), n_chains), dtype=f64, device=device)
+        io.d_state_out = _dev_ptr(state)
+        out["state"] = RwmState(state, i0 + n)
     ct = t._c()
     check(lib.mcmc_adapt_rwm_batch(C.byref(ct), C.byref(cfg), C.byref(io), _stream_ptr()))
     return out
+
+
+@dataclass
+class RwmState:
+    """Chain state of a Metropolis run (mcmc_rwm_io::d_state_out): a [state_doubles, n_chains] f64 CUDA
+    tensor and the number of iterations done.  No counterpart in the reference."""
+
+    array: "object"
+    iterations: int
+
+    def save(self, path):
+        np.savez(path, array=self.array.cpu().numpy(), iterations=np.int64(self.iterations))
+
+    @staticmethod
+    def load(path, device="cuda"):
+        torch = _torch()
+        with np.load(path) as f:
+            return RwmState(torch.tensor(f["array"], dtype=torch.float64, device=device), int(f["iterations"]))
 
 
 def target_eval_batch(target, x):
@@ -405,13 +440,15 @@ def init_normal(seed, n_chains, mean, sd, chain_offset=0, device="cuda"):
 
 def tmvn_gibbs_batch(n_chains, n_sweeps, mu, sigma, lower, upper, init_state, *, seed=0, thin=1, burn=0,
                      chain_offset=0, U=None, tail_safe=False, trace=True, final=True, moments=False,
-                     out=None, device="cuda"):
+                     out=None, device="cuda", sweep_offset=0):
     """Many independent rtmvnorm_gibbs chains in one launch (tmvrnormGibbs.cpp:91-142 per chain).
 
     init_state: length-d vector shared by all chains, or a [d, n_chains] CUDA tensor.
     U [n_sweeps, d, n_chains]: injected uniforms.  Returns CUDA tensors: trace
     [n_kept, d, n_chains], final_state [d, n_chains], status [n_chains], and with
     moments=True mean / m2 [d, n_chains] over sweeps > burn.
+    Resume: pass the previous call's final_state as init_state and sweep_offset = sweeps done; the
+    continuation is bit-identical to one uninterrupted call (the chain state of this sampler is x alone).
     """
     torch = _torch()
     f64 = torch.float64
@@ -428,7 +465,8 @@ def tmvn_gibbs_batch(n_chains, n_sweeps, mu, sigma, lower, upper, init_state, *,
         h_init, d_init = _vec(init_state), None
     if U is not None and tuple(U.shape) != (n_sweeps, d, n_chains):
         raise ValueError("U must be [n_sweeps, d, n_chains]")
-    n_kept = n_sweeps // int(thin)
+    j0 = int(sweep_offset)
+    n_kept = (j0 + n_sweeps) // int(thin) - j0 // int(thin)
 
     def buf(key, shape, dtype=f64, want=True):
         if not want:
@@ -442,7 +480,7 @@ def tmvn_gibbs_batch(n_chains, n_sweeps, mu, sigma, lower, upper, init_state, *,
     cfg = L.GibbsConfig(d=d, n_sweeps=n_sweeps, n_chains=n_chains, chain_offset=int(chain_offset),
                         thin=int(thin), burn=int(burn), seed=int(seed) & 0xFFFFFFFFFFFFFFFF,
                         rng_mode=L.MCMC_RNG_INJECTED if U is not None else L.MCMC_RNG_PHILOX,
-                        tail_safe=1 if tail_safe else 0)
+                        tail_safe=1 if tail_safe else 0, sweep_offset=j0)
     io = L.GibbsIO()
     io.h_mu, io.h_sigma, io.h_lower, io.h_upper = _p(mu), _p(sg), _p(lower), _p(upper)
     io.h_init_state = _p(h_init)

@@ -146,6 +146,10 @@ extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_co
     if (d > kMaxDimRwm) return set_error(MCMC_E_UNSUPPORTED, "adaptive RWM: d=%d above the limit %d", d, kMaxDimRwm);
     if (cfg->kernel < MCMC_KERNEL_AUTO || cfg->kernel > MCMC_KERNEL_PAIR)
         return set_error(MCMC_E_BAD_ARG, "unknown kernel choice %d", cfg->kernel);
+    if (cfg->iter_offset < 0 || (int64_t)cfg->iter_offset + cfg->n_iterations > 0x7fffffff)
+        return set_error(MCMC_E_BAD_ARG, "iter_offset=%d out of range", cfg->iter_offset);
+    if ((cfg->iter_offset > 0) != (io->d_state_in != nullptr))
+        return set_error(MCMC_E_BAD_ARG, "resume needs both iter_offset > 0 and d_state_in (a fresh start neither)");
     if (cfg->kernel == MCMC_KERNEL_LANE && d > kMaxLaneDimRwm)
         return set_error(MCMC_E_UNSUPPORTED, "one-chain-per-lane kernel: d=%d above its limit %d", d, kMaxLaneDimRwm);
     const bool use_block = cfg->kernel == MCMC_KERNEL_BLOCK || (cfg->kernel == MCMC_KERNEL_AUTO && d > kMaxLaneDimRwm);
@@ -189,13 +193,16 @@ extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_co
     a.d_scaling_sd = io->d_scaling_sd;
     a.d_scaling_multiplier = io->d_scaling_multiplier;
     a.d_rate_trace = io->d_rate_trace;
+    a.iter_offset = cfg->iter_offset;
+    a.d_state_in = io->d_state_in;
+    a.d_state_out = io->d_state_out;
 
-    // pow(adapt_size_cooling, i - adapt_size_start) for i = 0..n (adaptMCMC_source.cpp:123), host libm
+    // pow(adapt_size_cooling, i - adapt_size_start) for i = iter_offset + (0..n) (adaptMCMC_source.cpp:123), host libm
     double *d_cool = nullptr;
     if (cfg->adapt_size_start != 0) {
         std::vector<double> cool((size_t)cfg->n_iterations + 1);
         for (int i = 0; i <= cfg->n_iterations; ++i)
-            cool[i] = std::pow(cfg->adapt_size_cooling, i - cfg->adapt_size_start);
+            cool[i] = std::pow(cfg->adapt_size_cooling, cfg->iter_offset + i - cfg->adapt_size_start);
         MCMC_HIP_CHECK(hipMallocAsync((void **)&d_cool, cool.size() * sizeof(double), s));
         MCMC_HIP_CHECK(hipMemcpyAsync(d_cool, cool.data(), cool.size() * sizeof(double), hipMemcpyHostToDevice, s));
         MCMC_HIP_CHECK(hipStreamSynchronize(s)); // `cool` is a local: do not let the copy outlive it
@@ -212,6 +219,12 @@ extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_co
         if (rc == MCMC_OK && e != hipSuccess) rc = set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e));
     }
     return rc;
+}
+
+extern "C" int64_t mcmc_rwm_state_doubles(int32_t d)
+{
+    if (d < 1 || d > kMaxDimRwm) return set_error(MCMC_E_BAD_ARG, "mcmc_rwm_state_doubles: d=%d outside 1..%d", d, kMaxDimRwm);
+    return rwm_state_layout(d).TOTAL;
 }
 
 extern "C" int mcmc_rwm_streams(uint64_t seed, int64_t chain_offset, int64_t n_chains, int32_t n_iterations,
@@ -367,6 +380,8 @@ extern "C" int mcmc_tmvn_gibbs_batch(const mcmc_gibbs_config *cfg, const mcmc_gi
     if (cfg->n_sweeps < 1) return set_error(MCMC_E_BAD_ARG, "n_sweeps must be >= 1");
     if (cfg->thin < 1) return set_error(MCMC_E_BAD_ARG, "thin must be >= 1");
     if (cfg->burn < 0) return set_error(MCMC_E_BAD_ARG, "burn must be >= 0");
+    if (cfg->sweep_offset < 0 || (int64_t)cfg->sweep_offset + cfg->n_sweeps > 0x7fffffff)
+        return set_error(MCMC_E_BAD_ARG, "sweep_offset=%d out of range", cfg->sweep_offset);
     if (!io->h_mu || !io->h_sigma || !io->h_lower || !io->h_upper) return set_error(MCMC_E_BAD_ARG, "mu/sigma/lower/upper missing");
     if (!io->h_init_state && !io->d_init) return set_error(MCMC_E_BAD_ARG, "need h_init_state or d_init");
     if ((io->d_mean == nullptr) != (io->d_m2 == nullptr)) return set_error(MCMC_E_BAD_ARG, "d_mean and d_m2 come as a pair");
@@ -385,6 +400,7 @@ extern "C" int mcmc_tmvn_gibbs_batch(const mcmc_gibbs_config *cfg, const mcmc_gi
     a.n_sweeps = cfg->n_sweeps;
     a.thin = cfg->thin;
     a.burn = cfg->burn;
+    a.sweep_offset = cfg->sweep_offset;
     a.seed = cfg->seed;
     a.d_init = io->d_init;
     a.d_U = cfg->rng_mode == MCMC_RNG_INJECTED ? io->d_U : nullptr;

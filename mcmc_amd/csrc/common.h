@@ -47,6 +47,7 @@ struct GibbsArgs {
     int32_t n_sweeps;
     int32_t thin;
     int32_t burn;
+    int32_t sweep_offset;   // sweeps done before this launch (resume): Philox counter and thinning count from it
     uint64_t seed;
     const double *d_init;   // [d][n] or nullptr (then the shared start is used)
     const double *d_U;      // injected uniforms or nullptr (Philox)
@@ -104,6 +105,10 @@ struct RwmArgs {
     double *d_scaling_sd;
     double *d_scaling_multiplier;
     double *d_rate_trace;
+    // checkpoint / resume (rwm_state_layout below): iterations iter_offset+1 .. iter_offset+n_iterations run
+    int32_t iter_offset;
+    const double *d_state_in;
+    double *d_state_out;
 };
 
 #ifndef __HIPCC_RTC__
@@ -120,8 +125,9 @@ struct RwmParams {
 
 // How a Metropolis kernel gets onto the device: the kernels compiled into the library go through
 // hipLaunchKernelGGL, a run-time compiled user-target module through hipModuleLaunchKernel (rtc.hip).
-// `variant` is the kernel's bool template argument (FULL of the lane kernel, MOMENTS of the pair kernel).
-using RwmLauncher = std::function<hipError_t(bool variant, unsigned grid, unsigned block, size_t lds_bytes,
+// `variant` picks the instantiation: lane kernel 0 / 1 = FULL; pair kernel 0 = no moments, 1 = MOMENTS,
+// 2 = MOMENTS + STATE (checkpoint / resume).
+using RwmLauncher = std::function<hipError_t(int variant, unsigned grid, unsigned block, size_t lds_bytes,
                                              hipStream_t s, const RwmArgs &a, const double *d_prm)>;
 
 int launch_rwm_lane(const RwmArgs &a, const RwmParams &p, hipStream_t s);
@@ -140,6 +146,31 @@ int user_target_param_count(const void *handle, int d);
 
 // packed upper-triangular index, r <= c
 __host__ __device__ constexpr int tri(int r, int c) { return c * (c + 1) / 2 + r; }
+
+// ---- chain state as a checkpoint holds it: [slot][chain] doubles ------------------------------
+// theta[d] mean[d] covmat_empirical[T] (packed upper) R[T] (packed upper factor as the kernel keeps it),
+// then kRwmStateScalars scalars.  theta / mean / R are in the WRITING kernel's own representation
+// (the pair kernel keeps the Gaussian state centred, the lane kernel keeps R scaled), so a state is
+// resumed by the kernel that wrote it; ST_TAG says which and is checked on the device.
+enum RwmStateScalar {
+    ST_TAG = 0,   // MCMC_KERNEL_* of the writer
+    ST_ITER,      // iterations done
+    ST_TCUR,      // target(theta_current)
+    ST_RATE, ST_SD, ST_MULT, // acceptance_rate, scaling_sd, scaling_multiplier
+    ST_SEFF, ST_PRODR, ST_ROOT, // scale kept apart from R, prod diag(R), 1/sqrt((2 pi)^d det)
+    ST_WLO, ST_WHI, ST_WLEN,    // acceptance window: 64 outcomes as two 32-bit halves, and its length
+    ST_BASE,      // 1 when R factors covmat_empirical
+    ST_STATUS, ST_NSHAPE, ST_RESERVED,
+    kRwmStateScalars
+};
+struct RwmStateLayout {
+    int THETA, MEAN, C, R, S, TOTAL;
+};
+__host__ __device__ constexpr RwmStateLayout rwm_state_layout(int d)
+{
+    const int T = d * (d + 1) / 2;
+    return RwmStateLayout{0, d, 2 * d, 2 * d + T, 2 * d + 2 * T, 2 * d + 2 * T + (int)kRwmStateScalars};
+}
 
 // ---- parameter-block / LDS layouts of the one-chain-per-lane kernels ---------------------------
 // constexpr functions of (d, number of target parameters), so that the kernels use them as

@@ -57,8 +57,9 @@ __global__ __launch_bounds__(64, 3) void gibbs_kernel(const GibbsArgs a, const d
         const double *__restrict__ upper = mu + 3 * d;
         const double *__restrict__ inv_sd = mu + 5 * d;
         const double *__restrict__ P = mu + 6 * d;
-        const bool keep = a.d_trace && (j % a.thin) == 0;
-        const int64_t t = j / a.thin - 1;
+        const int ja = a.sweep_offset + j; // absolute sweep: Philox counter, thinning, status (resume)
+        const bool keep = a.d_trace && (ja % a.thin) == 0;
+        const int64_t t = ja / a.thin - a.sweep_offset / a.thin - 1;
         const bool mom = MOMENTS && j > a.burn;
         const double inv = mom ? 1.0 / (double)(j - a.burn) : 0.0;
         double ua = 0.0, ub = 0.0;
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(64, 3) void gibbs_kernel(const GibbsArgs a, const d
             if (inject) {
                 u = a.d_U[((int64_t)(j - 1) * d + i) * n + cc];
             } else {
-                if ((i & 1) == 0) philox_uniform2(key, gchain, (uint32_t)j, TAG_GIBBS, (uint32_t)(i >> 1), ua, ub);
+                if ((i & 1) == 0) philox_uniform2(key, gchain, (uint32_t)ja, TAG_GIBBS, (uint32_t)(i >> 1), ua, ub);
                 u = (i & 1) ? ub : ua;
             }
             // conditional mean mu_i + P_i (x[-i] - mu[-i])   (tmvrnormGibbs.cpp:124-127)
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(64, 3) void gibbs_kernel(const GibbsArgs a, const d
             const double mu_i = mu[i] + s;
             const double xi = rtnorm_draw_std<TAIL_SAFE>(u, mu_i, sd[i], inv_sd[i], lower[i], upper[i]);
             xc[i * 64 + lane] = xi - mu[i];
-            if (!isfinite(xi) && status == MCMC_CHAIN_OK) status = (j << 4) | MCMC_CHAIN_NONFINITE_STATE;
+            if (!isfinite(xi) && status == MCMC_CHAIN_OK) status = (ja << 4) | MCMC_CHAIN_NONFINITE_STATE;
             if (live) {
                 if (keep) a.d_trace[(t * d + i) * n + c] = xi;
                 if (j == a.n_sweeps && a.d_final) a.d_final[(int64_t)i * n + c] = xi;
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(512) void gibbs_wide_kernel(const GibbsArgs a, cons
             u = a.d_U[((int64_t)(j - 1) * d + i) * n + cc];
         } else {
             if ((i & 1) == 0) // coordinates are prepared in order, so the odd one finds its uniform waiting
-                philox_uniform2(PhiloxKey(a.seed), (uint64_t)(a.chain_offset + cc), (uint32_t)j, TAG_GIBBS, (uint32_t)(i >> 1), ua, ub);
+                philox_uniform2(PhiloxKey(a.seed), (uint64_t)(a.chain_offset + cc), (uint32_t)(a.sweep_offset + j), TAG_GIBBS, (uint32_t)(i >> 1), ua, ub);
             u = (i & 1) ? ub : ua;
         }
         slot[(p * 2 + 0) * 64] = s;
@@ -251,7 +252,8 @@ __global__ __launch_bounds__(512) void gibbs_wide_kernel(const GibbsArgs a, cons
             if (t + 1 < total) prepare(i1, i1 == 0 ? j + 1 : j, ring + r1 * W, p ^ 1);
         } else {
             const double *const row = ring + r0 * W;
-            const bool keep = a.d_trace && (j % a.thin) == 0;
+            const int ja = a.sweep_offset + j; // absolute sweep (resume)
+            const bool keep = a.d_trace && (ja % a.thin) == 0;
             const bool mom = MOMENTS && j > a.burn;
             // conditional mean mu_i + P_i (x[-i] - mu[-i])   (tmvrnormGibbs.cpp:124-127)
             const int prev = (i == 0) ? d - 1 : i - 1;
@@ -261,9 +263,9 @@ __global__ __launch_bounds__(512) void gibbs_wide_kernel(const GibbsArgs a, cons
             const double xi = rtnorm_draw_std<TAIL_SAFE>(u, mui + s, row[d + 1], row[d + 2], row[d + 3], row[d + 4]);
             xprev = xi - mui;
             xc[i * 64] = xprev;
-            if (!isfinite(xi) && status == MCMC_CHAIN_OK) status = (j << 4) | MCMC_CHAIN_NONFINITE_STATE;
+            if (!isfinite(xi) && status == MCMC_CHAIN_OK) status = (ja << 4) | MCMC_CHAIN_NONFINITE_STATE;
             if (live) {
-                if (keep) a.d_trace[((int64_t)(j / a.thin - 1) * d + i) * n + c] = xi;
+                if (keep) a.d_trace[((int64_t)(ja / a.thin - a.sweep_offset / a.thin - 1) * d + i) * n + c] = xi;
                 if (j == a.n_sweeps && a.d_final) a.d_final[(int64_t)i * n + c] = xi;
                 if (mom) { // running sums of the centred draw; no value comes back, so nothing waits for HBM
                     unsafeAtomicAdd(a.d_mean + (int64_t)i * n + c, xprev);

@@ -77,7 +77,8 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
     const int ass = a.adapt_size_start, ashs = a.adapt_shape_start;
     const int window = a.acceptance_window;
     const double wgt = a.acceptance_rate_weight;
-    const bool need_moments = ashs != 0 || (FULL && a.d_sigma_trace) || a.d_final_mean || a.d_final_cov;
+    const bool need_moments = ashs != 0 || (FULL && a.d_sigma_trace) || a.d_final_mean || a.d_final_cov || a.d_state_in || a.d_state_out;
+    const int i0 = a.iter_offset; // iterations done before this launch (checkpoint / resume)
     const double *__restrict__ tmean = prm + L.tmean();
     const double *__restrict__ H = prm + L.H();
     const int ti = tid & 15, tk = tid >> 4;
@@ -133,13 +134,52 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
     int win_len = 0;
     int32_t status = MCMC_CHAIN_OK, n_shape = 0;
     bool dead = false;
+    const RwmStateLayout SL = rwm_state_layout(d);
+    if (a.d_state_in) { // resume: everything the loop carries from one iteration to the next
+        const double *const sp = a.d_state_in + c;
+        __syncthreads();
+        if (tid < d) {
+            th[tid] = sp[(int64_t)(SL.THETA + tid) * n];
+            mn[tid] = sp[(int64_t)(SL.MEAN + tid) * n];
+        }
+        for (int e = tid; e < T; e += kBlockThreads) A[e] = sp[(int64_t)(SL.R + e) * n];
+#pragma unroll
+        for (int bb = 0; bb < NT; ++bb) {
+#pragma unroll
+            for (int aa = 0; aa <= bb; ++aa) {
+                const int r = 16 * aa + ti, cl = 16 * bb + tk;
+                if (r <= cl && cl < d) Ct[blk(aa, bb)] = sp[(int64_t)(SL.C + tri(r, cl)) * n];
+            }
+        }
+        const double *const ss = sp + (int64_t)SL.S * n;
+        t_cur = ss[ST_TCUR * n];
+        rate = ss[ST_RATE * n];
+        scaling_sd = ss[ST_SD * n];
+        scaling_multiplier = ss[ST_MULT * n];
+        s_eff = ss[ST_SEFF * n];
+        prodR = ss[ST_PRODR * n];
+        rootTerm = ss[ST_ROOT * n];
+        win_bits = ((uint64_t)(uint32_t)ss[ST_WHI * n] << 32) | (uint64_t)(uint32_t)ss[ST_WLO * n];
+        win_len = (int)ss[ST_WLEN * n];
+        base_emp = ss[ST_BASE * n] != 0.0;
+        status = (int32_t)ss[ST_STATUS * n];
+        n_shape = (int32_t)ss[ST_NSHAPE * n];
+        dead = status != MCMC_CHAIN_OK;
+        if (ss[ST_TAG * n] != (double)MCMC_KERNEL_BLOCK || ss[ST_ITER * n] != (double)i0) { // not a state this launch can continue
+            dead = true;
+            status = ((i0 + 1) << 4) | MCMC_CHAIN_BAD_STATE;
+            if (tid < d) th[tid] = __builtin_nan("");
+        }
+        __syncthreads();
+    }
 
-    for (int i = 1; i <= a.n_iterations; ++i) {
+    for (int i = i0 + 1; i <= i0 + a.n_iterations; ++i) {
+        const int li = i - i0; // position inside this launch: streams, diagnostics and the cooling table are per launch
         const double di = (double)i;
         // ---- adaptation of covmat_proposal (adaptMCMC_source.cpp:117-139), replicated ---------------
         bool rescale = false, refactor = false;
         if (ass != 0 && i >= ass && (ashs == 0 || mul_rn(rate, di) < (double)ashs)) {
-            scaling_multiplier = fm_exp(a.d_cool_pow[i] * (rate - 0.234));
+            scaling_multiplier = fm_exp(a.d_cool_pow[li] * (rate - 0.234));
             scaling_sd = mul_rn(scaling_sd, scaling_multiplier);
             scaling_sd = (a.max_scaling_sd < scaling_sd) ? a.max_scaling_sd : scaling_sd;
             const double s2 = mul_rn(scaling_sd, scaling_sd);
@@ -151,8 +191,8 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
             ++n_shape;
         }
         if (FULL && tid == 0) {
-            if (a.d_scaling_sd) a.d_scaling_sd[(int64_t)(i - 1) * n + c] = scaling_sd;
-            if (a.d_scaling_multiplier) a.d_scaling_multiplier[(int64_t)(i - 1) * n + c] = scaling_multiplier;
+            if (a.d_scaling_sd) a.d_scaling_sd[(int64_t)(li - 1) * n + c] = scaling_sd;
+            if (a.d_scaling_multiplier) a.d_scaling_multiplier[(int64_t)(li - 1) * n + c] = scaling_multiplier;
         }
 
         // ---- R = chol(covmat_proposal) when it was assigned (:153) --------------------------------
@@ -235,8 +275,8 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
 
         // ---- draws: d normals, then one uniform (:149-152,174) ----------------------------------------
         if (inject) {
-            if (tid < d) Y[tid] = a.d_Z[((int64_t)(i - 1) * d + tid) * n + c];
-            if (tid == 0) sc[0] = fm_log<true>(a.d_U[(int64_t)(i - 1) * n + c]);
+            if (tid < d) Y[tid] = a.d_Z[((int64_t)(li - 1) * d + tid) * n + c];
+            if (tid == 0) sc[0] = fm_log<true>(a.d_U[(int64_t)(li - 1) * n + c]);
         } else {
             const int nb = (d + 1) / 2;
             if (tid < nb) {
@@ -281,15 +321,15 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
             t_cur = t_prop;
         }
         if (FULL && tid == 0) {
-            if (a.d_accepted) a.d_accepted[(int64_t)(i - 1) * n + c] = accept ? 1 : 0;
-            if (a.d_log_acceptance) a.d_log_acceptance[(int64_t)(i - 1) * n + c] = la;
-            if (a.d_log_A) a.d_log_A[(int64_t)(i - 1) * n + c] = logA;
+            if (a.d_accepted) a.d_accepted[(int64_t)(li - 1) * n + c] = accept ? 1 : 0;
+            if (a.d_log_acceptance) a.d_log_acceptance[(int64_t)(li - 1) * n + c] = la;
+            if (a.d_log_A) a.d_log_A[(int64_t)(li - 1) * n + c] = logA;
         }
         __syncthreads();
 
         // ---- trace (:185) -------------------------------------------------------------------------------
         const bool keep = (i % a.thin) == 0;
-        const int64_t t = i / a.thin - 1;
+        const int64_t t = i / a.thin - i0 / a.thin - 1; // row inside this launch's trace
         if (a.d_trace && keep && tid < d) a.d_trace[(t * d + tid) * n + c] = th[tid];
 
         // ---- acceptance rate (:188-207), replicated ------------------------------------------------------
@@ -308,7 +348,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
         } else {
             rate = add_rn(mul_rn(rate, 1 - wgt), mul_rn(acc, wgt));
         }
-        if (FULL && a.d_rate_trace && tid == 0) a.d_rate_trace[(int64_t)(i - 1) * n + c] = rate;
+        if (FULL && a.d_rate_trace && tid == 0) a.d_rate_trace[(int64_t)(li - 1) * n + c] = rate;
 
         // ---- running mean / covariance (:210-214, update_sigma :42-45) ----------------------------------
         if (need_moments) {
@@ -369,6 +409,41 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
         if (a.d_acceptance_rate) a.d_acceptance_rate[c] = rate;
         if (a.d_status) a.d_status[c] = status;
         if (a.d_shape_iterations) a.d_shape_iterations[c] = n_shape;
+    }
+    if (a.d_state_out) {
+        double *const sp = a.d_state_out + c;
+        if (tid < d) {
+            sp[(int64_t)(SL.THETA + tid) * n] = th[tid];
+            sp[(int64_t)(SL.MEAN + tid) * n] = mn[tid];
+        }
+        for (int e = tid; e < T; e += kBlockThreads) sp[(int64_t)(SL.R + e) * n] = A[e];
+#pragma unroll
+        for (int bb = 0; bb < NT; ++bb) {
+#pragma unroll
+            for (int aa = 0; aa <= bb; ++aa) {
+                const int r = 16 * aa + ti, cl = 16 * bb + tk;
+                if (r <= cl && cl < d) sp[(int64_t)(SL.C + tri(r, cl)) * n] = Ct[blk(aa, bb)];
+            }
+        }
+        if (tid == 0) {
+            double *const ss = sp + (int64_t)SL.S * n;
+            ss[ST_TAG * n] = (double)MCMC_KERNEL_BLOCK;
+            ss[ST_ITER * n] = (double)(i0 + a.n_iterations);
+            ss[ST_TCUR * n] = t_cur;
+            ss[ST_RATE * n] = rate;
+            ss[ST_SD * n] = scaling_sd;
+            ss[ST_MULT * n] = scaling_multiplier;
+            ss[ST_SEFF * n] = s_eff;
+            ss[ST_PRODR * n] = prodR;
+            ss[ST_ROOT * n] = rootTerm;
+            ss[ST_WLO * n] = (double)(uint32_t)win_bits;
+            ss[ST_WHI * n] = (double)(uint32_t)(win_bits >> 32);
+            ss[ST_WLEN * n] = (double)win_len;
+            ss[ST_BASE * n] = base_emp ? 1.0 : 0.0;
+            ss[ST_STATUS * n] = (double)status;
+            ss[ST_NSHAPE * n] = (double)n_shape;
+            ss[ST_RESERVED * n] = 0.0;
+        }
     }
 }
 

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const dou
     const int ass = a.adapt_size_start, ashs = a.adapt_shape_start;
     const int window = a.acceptance_window;
     const double w = a.acceptance_rate_weight;
-    const bool need_moments = ashs != 0 || (FULL && a.d_sigma_trace) || a.d_final_mean || a.d_final_cov;
+    const bool need_moments = ashs != 0 || (FULL && a.d_sigma_trace) || a.d_final_mean || a.d_final_cov || a.d_state_in || a.d_state_out;
+    const int i0 = a.iter_offset; // iterations done before this launch (checkpoint / resume)
     // Stage the shared parameter block in LDS: the target alone needs d + d^2 values per iteration,
     // more than the ~100 SGPRs of a wave, so scalar loads would be spilled to VGPR lanes; from LDS
     // they arrive as same-address (broadcast) reads.
@@ -93,15 +94,47 @@ __global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const dou
     int win_len = 0;
     int32_t status = MCMC_CHAIN_OK, n_shape = 0;
     bool dead = false;
+    constexpr RwmStateLayout SL = rwm_state_layout(D);
+    if (a.d_state_in) { // resume: everything the loop carries from one iteration to the next
+        const double *const sp = a.d_state_in + cc;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            theta[k] = sp[(SL.THETA + k) * n];
+            Ml[k * 64] = sp[(SL.MEAN + k) * n];
+        }
+#pragma unroll
+        for (int e = 0; e < T; ++e) {
+            Cl[e * 64] = sp[(SL.C + e) * n];
+            R[e] = sp[(SL.R + e) * n];
+        }
+        const double *const ss = sp + (int64_t)SL.S * n;
+        t_cur = ss[ST_TCUR * n];
+        rate = ss[ST_RATE * n];
+        scaling_sd = ss[ST_SD * n];
+        scaling_multiplier = ss[ST_MULT * n];
+        rootTerm = ss[ST_ROOT * n];
+        win_bits = ((uint64_t)(uint32_t)ss[ST_WHI * n] << 32) | (uint64_t)(uint32_t)ss[ST_WLO * n];
+        win_len = (int)ss[ST_WLEN * n];
+        status = (int32_t)ss[ST_STATUS * n];
+        n_shape = (int32_t)ss[ST_NSHAPE * n];
+        dead = status != MCMC_CHAIN_OK;
+        if (ss[ST_TAG * n] != (double)MCMC_KERNEL_LANE || ss[ST_ITER * n] != (double)i0) { // not a state this launch can continue
+            dead = true;
+            status = ((i0 + 1) << 4) | MCMC_CHAIN_BAD_STATE;
+#pragma unroll
+            for (int k = 0; k < D; ++k) theta[k] = __builtin_nan("");
+        }
+    }
 
-    for (int i = 1; i <= a.n_iterations; ++i) {
+    for (int i = i0 + 1; i <= i0 + a.n_iterations; ++i) {
+        const int li = i - i0; // position inside this launch: streams, diagnostics and the cooling table are per launch
         const double *const pz = sh;
         const double di = (double)i;
         // ---- adaptation of covmat_proposal (adaptMCMC_source.cpp:117-139) ------------------
         bool dirty = false, use_emp = false;
         double s2 = 0.0;
         if (ass != 0 && i >= ass && (ashs == 0 || mul_rn(rate, di) < (double)ashs)) {
-            scaling_multiplier = exp(a.d_cool_pow[i] * (rate - 0.234));
+            scaling_multiplier = exp(a.d_cool_pow[li] * (rate - 0.234));
             scaling_sd = mul_rn(scaling_sd, scaling_multiplier);
             scaling_sd = (a.max_scaling_sd < scaling_sd) ? a.max_scaling_sd : scaling_sd; // std::min
             s2 = mul_rn(scaling_sd, scaling_sd);
@@ -116,8 +149,8 @@ __global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const dou
             use_emp = true;
             ++n_shape;
         }
-        if (FULL && a.d_scaling_sd && live) a.d_scaling_sd[(int64_t)(i - 1) * n + c] = scaling_sd;
-        if (FULL && a.d_scaling_multiplier && live) a.d_scaling_multiplier[(int64_t)(i - 1) * n + c] = scaling_multiplier;
+        if (FULL && a.d_scaling_sd && live) a.d_scaling_sd[(int64_t)(li - 1) * n + c] = scaling_sd;
+        if (FULL && a.d_scaling_multiplier && live) a.d_scaling_multiplier[(int64_t)(li - 1) * n + c] = scaling_multiplier;
 
         // ---- R = chol(covmat_proposal) when it was assigned (:153) -------------------------
         if (dirty && !dead) {
@@ -156,7 +189,7 @@ __global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const dou
         double Y[D], prop[D];
         if (inject) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) Y[k] = a.d_Z[((int64_t)(i - 1) * D + k) * n + cc];
+            for (int k = 0; k < D; ++k) Y[k] = a.d_Z[((int64_t)(li - 1) * D + k) * n + cc];
         } else {
 #pragma unroll
             for (int b = 0; 2 * b < D; ++b) {
@@ -191,7 +224,7 @@ __global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const dou
         // ---- accept / reject (:174-182) ------------------------------------------------------
         double A;
         if (inject) {
-            A = a.d_U[(int64_t)(i - 1) * n + cc];
+            A = a.d_U[(int64_t)(li - 1) * n + cc];
         } else {
             double u1;
             philox_uniform2(key, gchain, (uint32_t)i, TAG_RWM_UNIFORM, 0u, A, u1);
@@ -204,14 +237,14 @@ __global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const dou
             t_cur = t_prop;
         }
         if (FULL && live) {
-            if (a.d_accepted) a.d_accepted[(int64_t)(i - 1) * n + c] = accept ? 1 : 0;
-            if (a.d_log_acceptance) a.d_log_acceptance[(int64_t)(i - 1) * n + c] = la;
-            if (a.d_log_A) a.d_log_A[(int64_t)(i - 1) * n + c] = logA;
+            if (a.d_accepted) a.d_accepted[(int64_t)(li - 1) * n + c] = accept ? 1 : 0;
+            if (a.d_log_acceptance) a.d_log_acceptance[(int64_t)(li - 1) * n + c] = la;
+            if (a.d_log_A) a.d_log_A[(int64_t)(li - 1) * n + c] = logA;
         }
 
         // ---- trace (:185) -------------------------------------------------------------------
         const bool keep = (i % a.thin) == 0;
-        const int64_t t = i / a.thin - 1;
+        const int64_t t = i / a.thin - i0 / a.thin - 1; // row inside this launch's trace
         if (a.d_trace && keep && live) {
 #pragma unroll
             for (int k = 0; k < D; ++k) a.d_trace[(t * D + k) * n + c] = theta[k];
@@ -233,7 +266,7 @@ __global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const dou
         } else {
             rate = add_rn(mul_rn(rate, 1 - w), mul_rn(acc, w));
         }
-        if (FULL && a.d_rate_trace && live) a.d_rate_trace[(int64_t)(i - 1) * n + c] = rate;
+        if (FULL && a.d_rate_trace && live) a.d_rate_trace[(int64_t)(li - 1) * n + c] = rate;
 
         // ---- running mean / covariance (:210-214, update_sigma :42-45) ----------------------
         if (need_moments) {
@@ -280,6 +313,36 @@ __global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const dou
         if (a.d_acceptance_rate) a.d_acceptance_rate[c] = rate;
         if (a.d_status) a.d_status[c] = status;
         if (a.d_shape_iterations) a.d_shape_iterations[c] = n_shape;
+        if (a.d_state_out) {
+            double *const sp = a.d_state_out + c;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                sp[(SL.THETA + k) * n] = theta[k];
+                sp[(SL.MEAN + k) * n] = Ml[k * 64];
+            }
+#pragma unroll
+            for (int e = 0; e < T; ++e) {
+                sp[(SL.C + e) * n] = Cl[e * 64];
+                sp[(SL.R + e) * n] = R[e];
+            }
+            double *const ss = sp + (int64_t)SL.S * n;
+            ss[ST_TAG * n] = (double)MCMC_KERNEL_LANE;
+            ss[ST_ITER * n] = (double)(i0 + a.n_iterations);
+            ss[ST_TCUR * n] = t_cur;
+            ss[ST_RATE * n] = rate;
+            ss[ST_SD * n] = scaling_sd;
+            ss[ST_MULT * n] = scaling_multiplier;
+            ss[ST_SEFF * n] = 1.0;
+            ss[ST_PRODR * n] = 1.0;
+            ss[ST_ROOT * n] = rootTerm;
+            ss[ST_WLO * n] = (double)(uint32_t)win_bits;
+            ss[ST_WHI * n] = (double)(uint32_t)(win_bits >> 32);
+            ss[ST_WLEN * n] = (double)win_len;
+            ss[ST_BASE * n] = 0.0;
+            ss[ST_STATUS * n] = (double)status;
+            ss[ST_NSHAPE * n] = (double)n_shape;
+            ss[ST_RESERVED * n] = 0.0;
+        }
     }
 }
 
@@ -347,7 +410,7 @@ int launch_rwm_lane_with(const RwmArgs &a, const RwmParams &p, hipStream_t s, co
     const size_t ldsb = (size_t)L.LDS_DOUBLES * sizeof(double);
     const bool full = a.d_Z || a.d_sigma_trace || a.d_accepted || a.d_log_acceptance || a.d_log_A || a.d_scaling_sd ||
                       a.d_scaling_multiplier || a.d_rate_trace;
-    hipError_t e1 = launch(full, (unsigned)grid, 64u, ldsb, s, a, d_prm);
+    hipError_t e1 = launch(full ? 1 : 0, (unsigned)grid, 64u, ldsb, s, a, d_prm);
     hipError_t e2 = hipFreeAsync(d_prm, s);
     if (e1 != hipSuccess) return set_error(MCMC_E_HIP, "rwm_lane_kernel launch failed: %s", hipGetErrorString(e1));
     if (e2 != hipSuccess) return set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e2));
@@ -358,7 +421,7 @@ template <int D, int KIND>
 static int launch_rwm_lane_dk(const RwmArgs &a, const RwmParams &p, hipStream_t s)
 {
     return launch_rwm_lane_with(a, p, s, RwmLayout<D, KIND>::L,
-                                [](bool full, unsigned grid, unsigned block, size_t ldsb, hipStream_t st, const RwmArgs &aa,
+                                [](int full, unsigned grid, unsigned block, size_t ldsb, hipStream_t st, const RwmArgs &aa,
                                    const double *d_prm) {
                                     if (full)
                                         hipLaunchKernelGGL((rwm_lane_kernel<D, KIND, true>), dim3(grid), dim3(block), ldsb, st, aa, d_prm);

@@ -191,7 +191,9 @@ __device__ __forceinline__ bool flag_wait(int *flags, int which, int value)
     return ok;
 }
 
-template <int D, int KIND, bool MOMENTS>
+// STATE adds checkpoint / resume (d_state_in, d_state_out, iter_offset); it is a variant of its own because
+// the extra live values cost the C2 production kernel 3 % (measured).
+template <int D, int KIND, bool MOMENTS, bool STATE>
 __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmArgs a, const double *__restrict__ prm)
 {
     using Lay = PairLayout<D, KIND, MOMENTS>;
@@ -208,6 +210,13 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
     const int64_t cc = live ? c : n - 1; // lanes past the end shadow the last chain and store nothing
     const uint64_t gchain = (uint64_t)(a.chain_offset + cc);
     const int n_iter = a.n_iterations;
+    // checkpoint / resume: this launch runs iterations i0+1 .. i0+n_iter.  The hand-shake counters, the
+    // cooling table and the trace rows count positions inside the launch (li); Philox counters, the
+    // 1/i factors and the phase tests use the absolute iteration i0 + li.
+    const int i0 = STATE ? a.iter_offset : 0;
+    const double *const state_in = STATE ? a.d_state_in : nullptr;
+    double *const state_out = STATE ? a.d_state_out : nullptr;
+    constexpr RwmStateLayout SL = rwm_state_layout(D);
 
     for (int e = tid; e < Lay::SH; e += 128 * kPairGroups) lds[e] = prm[e];
     double *const G0 = lds + Lay::SH + group * Lay::GROUP;
@@ -216,6 +225,11 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
     double *const Xl = G0 + (Lay::DRAW + Lay::BACK) * 64 + lane; // covmat_empirical on request: Xl[e * 64]
     int *const flags = (int *)(G0 + (Lay::DRAW + Lay::BACK + Lay::CX) * 64);
     if (lane < 16 && !generator) flags[lane] = 0;
+    if (MOMENTS && generator) { // covmat_empirical: zero, or as the checkpoint holds it (before the barrier:
+                                // a resumed sampler may factor it in its prologue)
+#pragma unroll
+        for (int e = 0; e < T; ++e) Xl[e * 64] = state_in ? state_in[(int64_t)(SL.C + e) * n + cc] : 0.0;
+    }
     __syncthreads();
     const double *const sh = lds;
     const double *const tp = sh + Lay::TPRM;
@@ -232,18 +246,18 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
         double mean[MOMENTS ? D : 1];
         if (MOMENTS) {
 #pragma unroll
-            for (int e = 0; e < T; ++e) Xl[e * 64] = 0.0;
-#pragma unroll
-            for (int k = 0; k < D; ++k) mean[k] = (a.d_init ? a.d_init[(int64_t)k * n + cc] : prm[Lay::INIT + k]) - shift(k);
+            for (int k = 0; k < D; ++k)
+                mean[k] = state_in ? state_in[(int64_t)(SL.MEAN + k) * n + cc]
+                                       : (a.d_init ? a.d_init[(int64_t)k * n + cc] : prm[Lay::INIT + k]) - shift(k);
         }
         bool ok = true;
-        for (int i = 1; i <= n_iter + 1 && ok; ++i) {
+        for (int i = 1; i <= n_iter + 1 && ok; ++i) { // i: position inside this launch
             double Y[D], eq = 0.0, logA = 0.0;
             if (i <= n_iter) {
 #pragma unroll
                 for (int b = 0; 2 * b < D; ++b) {
                     double z0, z1;
-                    philox_normal2(key, gchain, (uint32_t)i, TAG_RWM_NORMAL, (uint32_t)b, z0, z1);
+                    philox_normal2(key, gchain, (uint32_t)(i0 + i), TAG_RWM_NORMAL, (uint32_t)b, z0, z1);
                     Y[2 * b] = z0;
                     if (2 * b + 1 < D) Y[2 * b + 1] = z1;
                 }
@@ -252,7 +266,7 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
                 for (int j = 0; j < D; ++j) q += Y[j] * Y[j];
                 eq = fm_exp(-0.5 * q);
                 double A, u1;
-                philox_uniform2(key, gchain, (uint32_t)i, TAG_RWM_UNIFORM, 0u, A, u1);
+                philox_uniform2(key, gchain, (uint32_t)(i0 + i), TAG_RWM_UNIFORM, 0u, A, u1);
                 logA = fm_log<false>(A); // A is in the open interval (0,1)
             }
             if (i <= n_iter) {
@@ -275,7 +289,7 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
             if (MOMENTS && i > 1) {
                 // update_sigma (:42-45) and the mean update (:212) of iteration i-1:
                 // C (i-2)/(i-1) + ((i-2)/(i-1)^2 r_a) r_b, one FMA per element
-                const double dm = (double)(i - 1);
+                const double dm = (double)(i0 + i - 1);
                 const double inv = fm_rcp(dm);
                 const double sfac = (dm - 1.0) * inv, bfac = sfac * inv;
                 double res[D];
@@ -306,6 +320,12 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
                         a.d_final_cov[(int64_t)(cl * D + r) * n + c] = Xl[(r <= cl ? tri(r, cl) : tri(cl, r)) * 64];
                 }
             }
+            if (state_out) { // this wave's half of the checkpoint: theta_mean (as kept: centred) and covmat_empirical
+#pragma unroll
+                for (int k = 0; k < D; ++k) state_out[(int64_t)(SL.MEAN + k) * n + c] = mean[k];
+#pragma unroll
+                for (int e = 0; e < T; ++e) state_out[(int64_t)(SL.C + e) * n + c] = Xl[e * 64];
+            }
         }
         return;
     }
@@ -332,23 +352,50 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
     int win_len = 0;
     int32_t status = MCMC_CHAIN_OK, n_shape = 0;
     bool dead = false, sync_ok = true;
-    int next_keep = a.thin; // next iteration whose state is stored
+    if (state_in) { // resume: everything the loop carries from one iteration to the next
+        const double *const sp = state_in + cc;
+#pragma unroll
+        for (int k = 0; k < D; ++k) theta[k] = sp[(int64_t)(SL.THETA + k) * n];
+#pragma unroll
+        for (int e = 0; e < T; ++e) R[e] = sp[(int64_t)(SL.R + e) * n];
+        const double *const ss = sp + (int64_t)SL.S * n;
+        t_cur = ss[ST_TCUR * n];
+        rate = ss[ST_RATE * n];
+        scaling_sd = ss[ST_SD * n];
+        s_eff = ss[ST_SEFF * n];
+        prodR = ss[ST_PRODR * n];
+        rootTerm = ss[ST_ROOT * n];
+        win_bits = ((uint64_t)(uint32_t)ss[ST_WHI * n] << 32) | (uint64_t)(uint32_t)ss[ST_WLO * n];
+        win_len = (int)ss[ST_WLEN * n];
+        base_emp = ss[ST_BASE * n] != 0.0;
+        status = (int32_t)ss[ST_STATUS * n];
+        n_shape = (int32_t)ss[ST_NSHAPE * n];
+        dead = status != MCMC_CHAIN_OK;
+        if (ss[ST_TAG * n] != (double)MCMC_KERNEL_PAIR || ss[ST_ITER * n] != (double)i0) { // not a state this launch can continue
+            dead = true;
+            status = ((i0 + 1) << 4) | MCMC_CHAIN_BAD_STATE;
+#pragma unroll
+            for (int k = 0; k < D; ++k) theta[k] = __builtin_nan("");
+        }
+    }
+    int next_keep = (i0 / a.thin + 1) * a.thin; // next iteration whose state is stored
     int64_t t_kept = 0;
 
-    // i = 0 is the prologue: the adaptation for iteration 1 only
-    for (int i = 0; i <= n_iter && sync_ok; ++i) {
+    // li = 0 is the prologue: the adaptation for iteration i0 + 1 only
+    for (int li = 0; li <= n_iter && sync_ok; ++li) {
+        const int i = i0 + li;
         // pow(adapt_size_cooling, (i+1) - adapt_size_start) for the adaptation at the end of this iteration:
         // the scalar load is issued here so that its latency is covered by the sampling step
-        const double cool = (ass != 0 && i < n_iter) ? a.d_cool_pow[i + 1] : 0.0;
-        if (i > 0) {
+        const double cool = (ass != 0 && li < n_iter) ? a.d_cool_pow[li + 1] : 0.0;
+        if (li > 0) {
             double Y[D];
-            sync_ok = flag_wait(flags, F_DRAW, i);
+            sync_ok = flag_wait(flags, F_DRAW, li);
 #pragma unroll
             for (int k = 0; k < D; ++k) Y[k] = Dl[k * 64];
             const double eq = Dl[D * 64];
             const double logA = Dl[(D + 1) * 64];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the draws are in registers
-            flag_set(flags, F_READ, i);
+            flag_set(flags, F_READ, li);
 
             // ---- proposal theta + Y chol(covmat_proposal) = theta + s (Y R) (:149-154) -----------
             double prop[D];
@@ -408,7 +455,7 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
 
         // ---- adaptation of covmat_proposal for iteration i + 1 (:117-139) -----------------------
         bool rescale = false, refactor = false;
-        if (i < n_iter) {
+        if (li < n_iter) {
             const int in = i + 1;
             const double din = (double)in;
             if (ass != 0 && in >= ass && (ashs == 0 || mul_rn(rate, din) < (double)ashs)) {
@@ -427,11 +474,11 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
         }
         // ---- hand theta of iteration i to the generator (update_sigma / mean, :210-214) -------------
         const bool want_c = MOMENTS && __builtin_amdgcn_ballot_w64(refactor) != 0;
-        if (MOMENTS && i > 0) {
-            if (i > 1) sync_ok = sync_ok && flag_wait(flags, F_BACKREAD, i - 1); // the generator has taken theta of iteration i-1
+        if (MOMENTS && li > 0) {
+            if (li > 1) sync_ok = sync_ok && flag_wait(flags, F_BACKREAD, li - 1); // the generator has taken theta of iteration i-1
 #pragma unroll
             for (int k = 0; k < D; ++k) Bl[k * 64] = theta[k];
-            flag_set(flags, F_THETA, i);
+            flag_set(flags, F_THETA, li);
         }
         if (rescale) {
             if (base_emp) { // back from the shape phase: the factor of covmat again
@@ -445,7 +492,7 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
         // ---- R = chol(covmat_empirical) for iteration i + 1 (:153) ------------------------------
         if constexpr (MOMENTS) {
             if (want_c) {
-                sync_ok = sync_ok && flag_wait(flags, F_C, i);
+                sync_ok = sync_ok && flag_wait(flags, F_C, li);
                 if (refactor) {
                     bool ok = true;
                     double prod = 1.0;
@@ -493,8 +540,32 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
         for (int k = 0; k < D; ++k)
             if (a.d_final_theta) a.d_final_theta[(int64_t)k * n + c] = theta[k] + shift(k);
         if (a.d_acceptance_rate) a.d_acceptance_rate[c] = rate;
-        if (a.d_status) a.d_status[c] = sync_ok ? status : (MCMC_CHAIN_SYNC_LOST | (n_iter << 4));
+        if (a.d_status) a.d_status[c] = sync_ok ? status : (MCMC_CHAIN_SYNC_LOST | ((i0 + n_iter) << 4));
         if (a.d_shape_iterations) a.d_shape_iterations[c] = n_shape;
+        if (MOMENTS && state_out) { // this wave's half of the checkpoint (the generator writes theta_mean and covmat_empirical)
+            double *const sp = state_out + c;
+#pragma unroll
+            for (int k = 0; k < D; ++k) sp[(int64_t)(SL.THETA + k) * n] = theta[k];
+#pragma unroll
+            for (int e = 0; e < T; ++e) sp[(int64_t)(SL.R + e) * n] = R[e];
+            double *const ss = sp + (int64_t)SL.S * n;
+            ss[ST_TAG * n] = (double)MCMC_KERNEL_PAIR;
+            ss[ST_ITER * n] = (double)(i0 + n_iter);
+            ss[ST_TCUR * n] = t_cur;
+            ss[ST_RATE * n] = rate;
+            ss[ST_SD * n] = scaling_sd;
+            ss[ST_MULT * n] = 1.0;
+            ss[ST_SEFF * n] = s_eff;
+            ss[ST_PRODR * n] = prodR;
+            ss[ST_ROOT * n] = rootTerm;
+            ss[ST_WLO * n] = (double)(uint32_t)win_bits;
+            ss[ST_WHI * n] = (double)(uint32_t)(win_bits >> 32);
+            ss[ST_WLEN * n] = (double)win_len;
+            ss[ST_BASE * n] = base_emp ? 1.0 : 0.0;
+            ss[ST_STATUS * n] = (double)(sync_ok ? status : (MCMC_CHAIN_SYNC_LOST | ((i0 + n_iter) << 4)));
+            ss[ST_NSHAPE * n] = (double)n_shape;
+            ss[ST_RESERVED * n] = 0.0;
+        }
     }
 }
 
@@ -504,7 +575,8 @@ int launch_rwm_pair_with(const RwmArgs &a, const RwmParams &p, hipStream_t s, in
                          const std::vector<double> &packed_tparams, const RwmLauncher &launch)
 {
     const int D = a.d;
-    const bool moments = a.adapt_shape_start != 0 || a.d_final_mean || a.d_final_cov;
+    const bool state = a.d_state_in || a.d_state_out;
+    const bool moments = a.adapt_shape_start != 0 || a.d_final_mean || a.d_final_cov || state;
     const PairLayoutRT L = pair_layout(D, n_packed, moments); // the HBM block does not depend on `moments`
     if ((int)packed_tparams.size() != n_packed) return set_error(MCMC_E_BAD_ARG, "pair kernel: target parameter block of the wrong size");
     std::vector<double> blob(L.TOTAL, 0.0);
@@ -524,7 +596,7 @@ int launch_rwm_pair_with(const RwmArgs &a, const RwmParams &p, hipStream_t s, in
     MCMC_HIP_CHECK(hipMemcpyAsync(d_prm, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, s));
     MCMC_HIP_CHECK(hipStreamSynchronize(s)); // blob is a local: do not let the copy outlive it
     const int64_t grid = (a.n_chains + 64 * kPairGroups - 1) / (64 * kPairGroups);
-    hipError_t e1 = launch(moments, (unsigned)grid, 128u * kPairGroups, (size_t)L.LDS_DOUBLES * sizeof(double), s, a, d_prm);
+    hipError_t e1 = launch(state ? 2 : (moments ? 1 : 0), (unsigned)grid, 128u * kPairGroups, (size_t)L.LDS_DOUBLES * sizeof(double), s, a, d_prm);
     hipError_t e2 = hipFreeAsync(d_prm, s);
     if (e1 != hipSuccess) return set_error(MCMC_E_HIP, "rwm_pair_kernel launch failed: %s", hipGetErrorString(e1));
     if (e2 != hipSuccess) return set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e2));
@@ -541,14 +613,15 @@ static int launch_rwm_pair_dk(const RwmArgs &a, const RwmParams &p, hipStream_t 
     PackedTarget<KIND, D>::pack(p.tparams, packed.data());
     return launch_rwm_pair_with(
         a, p, s, PackedTarget<KIND, D>::NP, packed,
-        [](bool moments, unsigned grid, unsigned block, size_t ldsb, hipStream_t st, const RwmArgs &aa, const double *d_prm) {
+        [](int variant, unsigned grid, unsigned block, size_t ldsb, hipStream_t st, const RwmArgs &aa, const double *d_prm) {
             auto go = [&](auto kern) {
                 hipError_t e0 = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
                 if (e0 != hipSuccess) return e0;
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(block), ldsb, st, aa, d_prm);
                 return hipGetLastError();
             };
-            return moments ? go(rwm_pair_kernel<D, KIND, true>) : go(rwm_pair_kernel<D, KIND, false>);
+            return variant == 2 ? go(rwm_pair_kernel<D, KIND, true, true>)
+                                : (variant == 1 ? go(rwm_pair_kernel<D, KIND, true, false>) : go(rwm_pair_kernel<D, KIND, false, false>));
         });
 }
 

@@ -34,7 +34,7 @@ constexpr uint32_t kUserMagic = 0x55544721u;
 struct UserModule {
     hipModule_t mod = nullptr;
     hipFunction_t lane[2] = {nullptr, nullptr}; // FULL = false / true
-    hipFunction_t pair[2] = {nullptr, nullptr}; // MOMENTS = false / true
+    hipFunction_t pair[3] = {nullptr, nullptr, nullptr}; // no moments / MOMENTS / MOMENTS + STATE
     hipFunction_t eval = nullptr;
 };
 
@@ -43,7 +43,7 @@ struct UserTarget {
     int d = 0, np = 0;
     bool has_pair = false;
     std::vector<char> code;
-    std::string lane_name[2], pair_name[2], eval_name;
+    std::string lane_name[2], pair_name[3], eval_name;
     std::mutex mu;
     std::map<int, UserModule> per_device; // loaded at first use on each device
 };
@@ -80,10 +80,9 @@ int get_module(UserTarget *u, UserModule **out)
     UserModule &m = u->per_device[dev];
     if (!m.mod) {
         MCMC_HIP_CHECK(hipModuleLoadData(&m.mod, u->code.data()));
-        for (int v = 0; v < 2; ++v) {
-            MCMC_HIP_CHECK(hipModuleGetFunction(&m.lane[v], m.mod, u->lane_name[v].c_str()));
-            if (u->has_pair) MCMC_HIP_CHECK(hipModuleGetFunction(&m.pair[v], m.mod, u->pair_name[v].c_str()));
-        }
+        for (int v = 0; v < 2; ++v) MCMC_HIP_CHECK(hipModuleGetFunction(&m.lane[v], m.mod, u->lane_name[v].c_str()));
+        for (int v = 0; v < 3 && u->has_pair; ++v)
+            MCMC_HIP_CHECK(hipModuleGetFunction(&m.pair[v], m.mod, u->pair_name[v].c_str()));
         MCMC_HIP_CHECK(hipModuleGetFunction(&m.eval, m.mod, u->eval_name.c_str()));
     }
     *out = &m;
@@ -116,7 +115,7 @@ int launch_rwm_lane_user(const RwmArgs &a, const RwmParams &p, hipStream_t s)
     const int rc = get_module(u, &m);
     if (rc != MCMC_OK) return rc;
     return launch_rwm_lane_with(a, p, s, lane_layout(a.d, u->np),
-                                [m](bool full, unsigned grid, unsigned block, size_t ldsb, hipStream_t st, const RwmArgs &aa,
+                                [m](int full, unsigned grid, unsigned block, size_t ldsb, hipStream_t st, const RwmArgs &aa,
                                     const double *d_prm) { return module_launch(m->lane[full], grid, block, ldsb, st, aa, d_prm); });
 }
 
@@ -129,7 +128,7 @@ int launch_rwm_pair_user(const RwmArgs &a, const RwmParams &p, hipStream_t s)
     const int rc = get_module(u, &m);
     if (rc != MCMC_OK) return rc;
     return launch_rwm_pair_with(a, p, s, u->np, p.tparams,
-                                [m](bool moments, unsigned grid, unsigned block, size_t ldsb, hipStream_t st, const RwmArgs &aa,
+                                [m](int moments, unsigned grid, unsigned block, size_t ldsb, hipStream_t st, const RwmArgs &aa,
                                     const double *d_prm) { return module_launch(m->pair[moments], grid, block, ldsb, st, aa, d_prm); });
 }
 
@@ -180,12 +179,14 @@ extern "C" int mcmc_target_compile(const char *source, int32_t d, int32_t n_para
     up->np = n_params;
     up->has_pair = has_pair;
     const std::string ds = std::to_string(d), ks = std::to_string(MCMC_TARGET_USER);
-    std::string expr_lane[2], expr_pair[2], expr_eval = "mcmc::target_eval_kernel<" + ds + ", " + ks + ">";
+    std::string expr_lane[2], expr_pair[3], expr_eval = "mcmc::target_eval_kernel<" + ds + ", " + ks + ">";
     for (int v = 0; v < 2; ++v) {
         expr_lane[v] = "mcmc::rwm_lane_kernel<" + ds + ", " + ks + ", " + (v ? "true" : "false") + ">";
-        expr_pair[v] = "mcmc::rwm_pair_kernel<" + ds + ", " + ks + ", " + (v ? "true" : "false") + ">";
         hiprtcAddNameExpression(prog, expr_lane[v].c_str());
-        if (has_pair) hiprtcAddNameExpression(prog, expr_pair[v].c_str());
+    }
+    for (int v = 0; v < 3 && has_pair; ++v) {
+        expr_pair[v] = "mcmc::rwm_pair_kernel<" + ds + ", " + ks + ", " + (v ? "true" : "false") + ", " + (v == 2 ? "true" : "false") + ">";
+        hiprtcAddNameExpression(prog, expr_pair[v].c_str());
     }
     hiprtcAddNameExpression(prog, expr_eval.c_str());
 
@@ -212,10 +213,8 @@ extern "C" int mcmc_target_compile(const char *source, int32_t d, int32_t n_para
         if (hiprtcGetLoweredName(prog, expr.c_str(), &nm) != HIPRTC_SUCCESS || !nm) ok = false;
         else out = nm;
     };
-    for (int v = 0; v < 2; ++v) {
-        lowered(expr_lane[v], up->lane_name[v]);
-        if (has_pair) lowered(expr_pair[v], up->pair_name[v]);
-    }
+    for (int v = 0; v < 2; ++v) lowered(expr_lane[v], up->lane_name[v]);
+    for (int v = 0; v < 3 && has_pair; ++v) lowered(expr_pair[v], up->pair_name[v]);
     lowered(expr_eval, up->eval_name);
     size_t code_size = 0;
     if (ok && hiprtcGetCodeSize(prog, &code_size) == HIPRTC_SUCCESS && code_size) {
