@@ -17,6 +17,8 @@
 //     the loop and then spilling them to VGPR lanes (v_readlane in the hot loop).
 //   * samples: one coalesced store per coordinate and kept sweep, trace[(t*d+k)*n + c] --
 //     512 contiguous bytes per wavefront.
+#include <cstdlib>
+
 #include "common.h"
 #include "normal_cdf.h"
 #include "philox.h"
@@ -176,24 +178,29 @@ __device__ __forceinline__ double dot_range(const double *row, const double *xc,
 
 constexpr int kWideMaxPrefetch = 3; // ceil(W / threads) at d = 256 (one group, 128 threads)
 
+// G chain groups per workgroup, each with one draw wave (waves 0..G-1) and NDOT dot waves (wave G + part*G + group
+// sums the k-range `part` of the conditional-mean sum).
 template <bool TAIL_SAFE, bool MOMENTS>
-__global__ __launch_bounds__(512) void gibbs_wide_kernel(const GibbsArgs a, const double *__restrict__ rows, int W)
+__global__ __launch_bounds__(1024) void gibbs_wide_kernel(const GibbsArgs a, const double *__restrict__ rows, int W, int G, int NDOT)
 {
-    extern __shared__ double lds[]; // [3][W] row ring, [G][2][2][64] hand-over slots, then per group the centred state [d][64]
+    extern __shared__ double lds[]; // [3][W] row ring, [G][2][NDOT+1][64] hand-over slots, then per group the centred state [d][64]
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int G = nthreads >> 7;
     const bool dotter = wave >= G;
-    const int group = dotter ? wave - G : wave;
+    const int group = dotter ? (wave - G) % G : wave;
+    const int part = dotter ? (wave - G) / G : 0;
+    const int NS = NDOT + 1; // slots per parity: NDOT partial sums, then the uniform
     const int d = a.d;
+    const int chunk = ((d + NDOT - 1) / NDOT + 7) & ~7;
+    const int ka = part * chunk < d ? part * chunk : d, kb = ka + chunk < d ? ka + chunk : d; // this dot wave's k-range
     const int64_t c = ((int64_t)blockIdx.x * G + group) * 64 + lane;
     const int64_t n = a.n_chains;
     const bool live = c < n;
     const int64_t cc = live ? c : n - 1; // lanes past the end shadow the last chain and store nothing
     double *const ring = lds;
-    double *const slot = lds + 3 * W + (size_t)group * 256 + lane;           // [parity][0: sum, 1: u][lane]
-    double *const xc = lds + 3 * W + (size_t)G * 256 + (size_t)group * d * 64 + lane; // element k at xc[k * 64]
+    double *const slot = lds + 3 * W + (size_t)group * (2 * NS * 64) + lane;  // [parity][part sums.., u][lane]
+    double *const xc = lds + 3 * W + (size_t)G * (2 * NS * 64) + (size_t)group * d * 64 + lane; // element k at xc[k * 64]
     const double *const init = rows + (size_t)d * W;
     const int64_t total = (int64_t)a.n_sweeps * d; // steps; step t handles coordinate t % d of sweep t / d + 1
 
@@ -216,9 +223,16 @@ __global__ __launch_bounds__(512) void gibbs_wide_kernel(const GibbsArgs a, cons
     auto prepare = [&](int i, int j, const double *row, int p) {
         const int skip = (i == 0) ? d - 1 : i - 1; // the element the draw wave is still changing
         const int lo = skip < i ? skip : i, hi = skip < i ? i : skip; // d >= 3: two distinct indices
-        double s = dot_range(row, xc, 0, lo, 0.0);
-        s = dot_range(row, xc, lo + 1, hi, s);
-        s = dot_range(row, xc, hi + 1, d, s);
+        auto seg = [&](int k0, int k1, double acc) { // [k0, k1) cut to this wave's range
+            k0 = k0 > ka ? k0 : ka;
+            k1 = k1 < kb ? k1 : kb;
+            return k0 < k1 ? dot_range(row, xc, k0, k1, acc) : acc;
+        };
+        double s = seg(0, lo, 0.0);
+        s = seg(lo + 1, hi, s);
+        s = seg(hi + 1, d, s);
+        slot[(p * NS + part) * 64] = s;
+        if (part != 0) return; // the uniform is the first dot wave's job
         double u;
         if (a.d_U) {
             u = a.d_U[((int64_t)(j - 1) * d + i) * n + cc];
@@ -227,8 +241,7 @@ __global__ __launch_bounds__(512) void gibbs_wide_kernel(const GibbsArgs a, cons
                 philox_uniform2(PhiloxKey(a.seed), (uint64_t)(a.chain_offset + cc), (uint32_t)(a.sweep_offset + j), TAG_GIBBS, (uint32_t)(i >> 1), ua, ub);
             u = (i & 1) ? ub : ua;
         }
-        slot[(p * 2 + 0) * 64] = s;
-        slot[(p * 2 + 1) * 64] = u;
+        slot[(p * NS + NDOT) * 64] = u;
     };
 
     if (dotter) prepare(0, 1, ring, 0);
@@ -257,8 +270,10 @@ __global__ __launch_bounds__(512) void gibbs_wide_kernel(const GibbsArgs a, cons
             const bool mom = MOMENTS && j > a.burn;
             // conditional mean mu_i + P_i (x[-i] - mu[-i])   (tmvrnormGibbs.cpp:124-127)
             const int prev = (i == 0) ? d - 1 : i - 1;
-            const double s = slot[(p * 2 + 0) * 64] + row[prev] * xprev;
-            const double u = slot[(p * 2 + 1) * 64];
+            double s = slot[(p * NS) * 64];
+            for (int q = 1; q < NDOT; ++q) s += slot[(p * NS + q) * 64];
+            s += row[prev] * xprev;
+            const double u = slot[(p * NS + NDOT) * 64];
             const double mui = row[d];
             const double xi = rtnorm_draw_std<TAIL_SAFE>(u, mui + s, row[d + 1], row[d + 2], row[d + 3], row[d + 4]);
             xprev = xi - mui;
@@ -374,10 +389,21 @@ int launch_gibbs(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipSt
         }
         for (int k = 0; k < d; ++k) rows[(size_t)d * W + k] = p.init[k];
         const size_t state = (size_t)d * 64 * sizeof(double), rowb = (size_t)3 * W * sizeof(double);
-        int nw = (int)((160 * 1024 - rowb - 4 * 2048) / state); // chain groups per workgroup
+        int nw = (int)((160 * 1024 - rowb - 4 * 8192) / state); // chain groups per workgroup (slots: at most 8 KB each)
         nw = nw < 1 ? 1 : (nw > 4 ? 4 : nw);
-        if ((W + nw * 128 - 1) / (nw * 128) > kWideMaxPrefetch) return set_error(MCMC_E_UNSUPPORTED, "gibbs: d=%d too wide", d);
-        const size_t ldsw = rowb + (size_t)nw * 2048 + nw * state;
+        // dot waves per group: nw (1 + ndot) waves per workgroup, at most 16; a function of d only, so that results
+        // do not depend on how chains are split over launches
+        // (measured at d = 128, two groups: 1 / 2 / 3 / 5 / 7 dot waves -> 507 / 393 / 403 / 522 / 470 ms; beyond two the
+        // per-step barrier over more waves costs more than the shorter sums save, and the draw wave is the bound)
+        int ndot = 16 / nw - 1;
+        ndot = ndot > 2 ? 2 : ndot;
+        if (const char *env = std::getenv("MCMC_GIBBS_NDOT")) { // tuning hook
+            const int v = std::atoi(env);
+            if (v >= 1 && v <= 7 && nw * (1 + v) <= 16) ndot = v;
+        }
+        const int threads = nw * (1 + ndot) * 64;
+        if ((W + threads - 1) / threads > kWideMaxPrefetch) return set_error(MCMC_E_UNSUPPORTED, "gibbs: d=%d too wide", d);
+        const size_t ldsw = rowb + (size_t)nw * (2 * (ndot + 1) * 64) * sizeof(double) + nw * state;
         double *d_rows = nullptr;
         MCMC_HIP_CHECK(hipMallocAsync((void **)&d_rows, rows.size() * sizeof(double), s));
         MCMC_HIP_CHECK(hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, s));
@@ -385,7 +411,7 @@ int launch_gibbs(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipSt
         const int64_t gridw = (a.n_chains + 64 * nw - 1) / (64 * nw);
         auto gow = [&](auto kern) -> int {
             MCMC_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
-            hipLaunchKernelGGL(kern, dim3((unsigned)gridw), dim3(128 * nw), ldsw, s, a, (const double *)d_rows, W);
+            hipLaunchKernelGGL(kern, dim3((unsigned)gridw), dim3(threads), ldsw, s, a, (const double *)d_rows, W, nw, ndot);
             MCMC_HIP_CHECK(hipGetLastError());
             return MCMC_OK;
         };
