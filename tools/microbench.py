@@ -176,3 +176,8 @@ def c1_single_chain():
 
 if __name__ == "__main__" and "c1" in sys.argv:
     c1_single_chain()
+
+
+if __name__ == "__main__" and "gibbs_mid" in sys.argv:  # crossover between the lane kernel (d <= 32) and the wide kernel
+    for d in (16, 24, 32, 34, 48, 64, 96):
+        gibbs(d, 1 << 18, 40, trace=False)
