@@ -23,11 +23,12 @@
 // scaling_sd^2 covmat every iteration, adaptMCMC_source.cpp:129,153: d^3/3 flops for the same matrix).
 //
 // The factorization is the right-looking (outer-product) Cholesky with the trailing matrix held in
-// registers: at step j the owners of row j publish it (unscaled, pivot included) in a double-buffered
-// LDS row, ONE barrier, then every thread scales the 2 NT entries it needs by 1/sqrt(pivot) and
-// updates its tile with NT(NT+1)/2 FMAs; the owners also store the finished row of R to LDS.  Same
-// arithmetic per element as the reference's dpotrf, different summation order than the one-lane
-// kernel; FP64 MFMA blocking is the planned replacement.
+// registers: at step j the owners of row j (a quarter of ONE wave) publish it in a double-buffered
+// LDS row -- unscaled, zero up to the pivot, the pivot in a slot of its own -- ONE barrier, then every
+// thread reads the 2 NT entries it needs without any range test, scales one side by 1/pivot and
+// updates its tile with at most NT(NT+1)/2 FMAs (a_ik - (a_ji / a_jj) a_jk: the square root is off the
+// critical path); the owners alone take the square root and store the finished row of R to LDS.
+// The step is instruction-bound, so what counts is the number of instructions around the FMAs.
 #include "common.h"
 #include "philox.h"
 #include "targets.h"
@@ -48,7 +49,7 @@ struct BlockLayout {
     __host__ __device__ int tmean() const { return d + 2 * T + 1; }
     __host__ __device__ int H() const { return 2 * d + 2 * T + 1; }
     __host__ __device__ int total() const { return 2 * d + 2 * T + 1 + d * d; }
-    __host__ __device__ int lds_doubles() const { return T + 6 * d + 8 + 2 * 16 * ((d + 15) / 16); }
+    __host__ __device__ int lds_doubles() const { return T + 6 * d + 8 + 2 * (16 * ((d + 15) / 16) + 2) + 16; }
 };
 
 template <int NT, bool FULL>
@@ -67,7 +68,9 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
     double *const v = pr + d;     // scratch: x - mean of the target, residual
     double *const w = v + d;      // scratch: v_i * (H v)_i
     double *const sc = w + d;     // sc[0] = log(A)
-    double *const raw = sc + 8;   // two unscaled pivot rows (double buffer), 16 NT doubles each
+    double *const raw = sc + 8;   // two unscaled pivot rows (double buffer): 16 NT entries, the pivot, one pad
+    constexpr int RS = 16 * NT + 2;
+    double *const pp = raw + 2 * RS; // 16 partial products of diag(R)
     constexpr int NB = NT * (NT + 1) / 2;
     const int64_t c = blockIdx.x;
     const int64_t n = a.n_chains;
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
     const int i0 = a.iter_offset; // iterations done before this launch (checkpoint / resume)
     const double *__restrict__ tmean = prm + L.tmean();
     const double *__restrict__ H = prm + L.H();
-    const int ti = tid & 15, tk = tid >> 4;
+    const int ti = tid >> 4, tk = tid & 15; // tile row / column: the 16 owners of a row sit in one wave
 
     // covmat_empirical tile (registers) and the working copy the factorization consumes
     double Ct[NB], At[NB];
@@ -210,48 +213,57 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
 #pragma unroll
             for (int q = 0; q < NB; ++q) At[q] = Ct[q];
             bool ok = true;
-            double prod = 1.0;
+            double prod = 1.0; // diag(R) entries this thread finished (the owner with tk == 0)
 #pragma unroll
             for (int a0 = 0; a0 < NT; ++a0) {
                 for (int jt = 0; jt < 16; ++jt) {
                     const int j = 16 * a0 + jt;
                     if (j >= d) break;
-                    double *const row = raw + (j & 1) * (16 * NT);
-                    if (ti == jt) { // owners of row j publish it unscaled (pivot included)
+                    double *const row = raw + (j & 1) * RS;
+                    const bool owner = ti == jt;
+                    if (owner) { // publish row j: zero up to and including the pivot, so that readers need no range test
 #pragma unroll
                         for (int bb = a0; bb < NT; ++bb) {
                             const int kk = 16 * bb + tk;
-                            if (kk >= j && kk < d) row[kk] = At[blk(a0, bb)];
+                            const double val = At[blk(a0, bb)]; // entries beyond d are exactly zero
+                            if (kk == j) row[16 * NT] = val;
+                            row[kk] = (kk > j) ? val : 0.0;
                         }
                     }
                     __syncthreads();
-                    const double ajj = row[j];
+                    const double ajj = row[16 * NT];
                     ok = ok && (ajj > 0.0);
-                    double rjj, rinv;
-                    fm_sqrt_rsq(ajj, rjj, rinv);
-                    prod *= rjj;
+                    const double inv = fm_rcp(ajj);
                     double ri[NT], rk[NT];
 #pragma unroll
                     for (int x = a0; x < NT; ++x) {
-                        const int ii = 16 * x + ti, kk = 16 * x + tk;
-                        ri[x] = (ii > j && ii < d) ? row[ii] * rinv : 0.0;
-                        rk[x] = (kk > j && kk < d) ? row[kk] * rinv : 0.0;
+                        ri[x] = row[16 * x + ti] * inv;
+                        rk[x] = row[16 * x + tk];
                     }
-                    if (ti == jt) { // finished row j of R -> LDS (packed by columns)
+                    if (owner) { // finished row j of R -> LDS (packed by columns)
+                        double rjj, rinv;
+                        fm_sqrt_rsq(ajj, rjj, rinv);
 #pragma unroll
                         for (int bb = a0; bb < NT; ++bb) {
                             const int kk = 16 * bb + tk;
-                            if (kk > j && kk < d) A[tri(j, kk)] = rk[bb];
-                            if (kk == j) A[tri(j, j)] = rjj;
+                            if (kk > j && kk < d) A[tri(j, kk)] = rk[bb] * rinv;
+                            if (kk == j) {
+                                A[tri(j, j)] = rjj;
+                                prod *= rjj;
+                            }
                         }
                     }
 #pragma unroll
                     for (int bb = a0; bb < NT; ++bb) {
 #pragma unroll
-                        for (int aa = a0; aa <= bb; ++aa) At[blk(aa, bb)] -= ri[aa] * rk[bb];
+                        for (int aa = a0; aa <= bb; ++aa) At[blk(aa, bb)] = fma(-ri[aa], rk[bb], At[blk(aa, bb)]);
                     }
                 }
             }
+            if (tk == 0) pp[ti] = prod;
+            __syncthreads();
+            prod = 1.0;
+            for (int q = 0; q < 16; ++q) prod *= pp[q];
             __syncthreads();
             prodR = prod;
             base_emp = true;
