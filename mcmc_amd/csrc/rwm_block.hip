@@ -49,7 +49,7 @@ struct BlockLayout {
     __host__ __device__ int tmean() const { return d + 2 * T + 1; }
     __host__ __device__ int H() const { return 2 * d + 2 * T + 1; }
     __host__ __device__ int total() const { return 2 * d + 2 * T + 1 + d * d; }
-    __host__ __device__ int lds_doubles() const { return T + 6 * d + 8 + 2 * (16 * ((d + 15) / 16) + 2) + 16; }
+    __host__ __device__ int lds_doubles() const { return T + 5 * d + 16 + 2 * (16 * ((d + 15) / 16) + 2) + 16 + 256; }
 };
 
 template <int NT, bool FULL>
@@ -66,12 +66,17 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
     double *const Y = mn + d;     // proposal normals
     double *const pr = Y + d;     // theta_propose
     double *const v = pr + d;     // scratch: x - mean of the target, residual
-    double *const w = v + d;      // scratch: v_i * (H v)_i
-    double *const sc = w + d;     // sc[0] = log(A)
-    double *const raw = sc + 8;   // two unscaled pivot rows (double buffer): 16 NT entries, the pivot, one pad
+    double *const sc = v + d;     // sc[0] = log(A); sc[4..7], sc[8..11]: per-wave partial sums
+    double *const raw = sc + 16;  // two unscaled pivot rows (double buffer): 16 NT entries, the pivot, one pad
     constexpr int RS = 16 * NT + 2;
     double *const pp = raw + 2 * RS; // 16 partial products of diag(R)
+    double *const part = pp + 16;    // [2][128] halves of the target's matrix-vector product
     constexpr int NB = NT * (NT + 1) / 2;
+    // The matrix-vector products and sums of an iteration are either spread over all four waves (SPLIT) or done
+    // one thread per row with fewer barriers.  Measured, size phase, chain-iterations/s split vs not:
+    // d = 32: 1.59e8 / 1.78e8, d = 48: 1.29e8 / 1.00e8, d = 64: 8.2e7 / 9.6e7 (the split form drops to two waves
+    // per SIMD there), d = 72: 7.1e7 / 5.0e7, d = 100: 6.1e7 / 3.8e7, d = 128: 5.0e7 / 3.2e7.
+    constexpr bool SPLIT = NT >= 5 || NT == 3;
     const int64_t c = blockIdx.x;
     const int64_t n = a.n_chains;
     const uint64_t gchain = (uint64_t)(a.chain_offset + c);
@@ -98,27 +103,62 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
     }
     __syncthreads();
 
-    // -0.5 (x - m)^T H (x - m), rows summed in the oracle's order; result replicated in every thread
+    // sum over the wavefront, every lane gets it
+    auto wave_sum = [](double x) -> double {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+        return x;
+    };
+    // -0.5 (x - m)^T H (x - m); result replicated in every thread.  (H v) is formed by all four waves: waves 0-1
+    // sum the columns [0, jm) of their row, waves 2-3 the columns [jm, d), eight coalesced loads in flight each;
+    // the d products v_i (H v)_i are summed by a wave reduction + four partial sums in LDS.  (A 100-step serial
+    // sum replicated in every thread, as in the first version, costs ~11 cycles per step: the iteration is a
+    // chain of such latencies, not of flops.)
     auto target = [&](const double *x) -> double {
         if (tid < d) v[tid] = x[tid] - tmean[tid];
         __syncthreads();
-        if (tid < d) {
-            double s = 0.0;
-            int j = 0;
-            for (; j + 8 <= d; j += 8) { // eight coalesced loads in flight, then the oracle's left-to-right sum
-                double h[8];
+        if constexpr (!SPLIT) { // small d: one thread per row, left-to-right sums (short chains; fewer barriers win)
+            if (tid < d) {
+                double s = 0.0;
+                int j = 0;
+                for (; j + 8 <= d; j += 8) {
+                    double h[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) h[u] = H[(int64_t)(j + u) * d + tid];
+                    for (int u = 0; u < 8; ++u) h[u] = H[(int64_t)(j + u) * d + tid];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) s += h[u] * v[j + u];
+                    for (int u = 0; u < 8; ++u) s += h[u] * v[j + u];
+                }
+                for (; j < d; ++j) s += H[(int64_t)j * d + tid] * v[j];
+                part[tid] = v[tid] * s;
             }
-            for (; j < d; ++j) s += H[(int64_t)j * d + tid] * v[j];
-            w[tid] = mul_rn(v[tid], s);
+            __syncthreads();
+            double q = 0.0;
+            for (int i = 0; i < d; ++i) q += part[i];
+            return -0.5 * q;
+        } else {
+            const int half = tid >> 7, row = tid & 127;
+            if (row < d) {
+                const int jm = (d + 1) >> 1;
+                int j = half ? jm : 0;
+                const int j1 = half ? d : jm;
+                double s = 0.0;
+                for (; j + 8 <= j1; j += 8) {
+                    double h[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) h[u] = H[(int64_t)(j + u) * d + row];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s = fma(h[u], v[j + u], s);
+                }
+                for (; j < j1; ++j) s = fma(H[(int64_t)j * d + row], v[j], s);
+                part[half * 128 + row] = s;
+            }
+            __syncthreads();
+            const double wv = (tid < d) ? v[tid] * (part[tid] + part[128 + tid]) : 0.0;
+            const double ws = wave_sum(wv);
+            if ((tid & 63) == 0) sc[4 + (tid >> 6)] = ws;
+            __syncthreads();
+            return -0.5 * ((sc[4] + sc[5]) + (sc[6] + sc[7]));
         }
-        __syncthreads();
-        double q = 0.0;
-        for (int i = 0; i < d; ++i) q = add_rn(q, w[i]);
-        return -0.5 * q;
     };
 
     double rootTerm = prm[L.root0()];
@@ -304,17 +344,36 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
         }
         __syncthreads();
 
-        // ---- proposal theta + Y * R (:153-154): thread j owns column j ---------------------------------
-        if (tid < d) {
-            const double *col = A + tri(0, tid);
+        // ---- proposal theta + Y * R (:153-154) --------------------------------------------------------
+        double q;
+        if constexpr (!SPLIT) { // thread j owns column j
+            if (tid < d) {
+                const double *col = A + tri(0, tid);
+                double s = 0.0;
+                for (int k = 0; k <= tid; ++k) s += Y[k] * col[k];
+                pr[tid] = th[tid] + s_eff * s;
+            }
+            q = 0.0;
+            for (int k = 0; k < d; ++k) q += Y[k] * Y[k];
+        } else { // two threads per column, each half of the k range
+            const int jc = tid >> 1, h = tid & 1;
             double s = 0.0;
-            for (int k = 0; k <= tid; ++k) s += Y[k] * col[k];
-            pr[tid] = th[tid] + s_eff * s;
+            if (jc < d) {
+                const double *col = A + tri(0, jc);
+                const int m = (jc + 1) >> 1;
+                const int k1 = h ? jc + 1 : m;
+                for (int k = h ? m : 0; k < k1; ++k) s = fma(Y[k], col[k], s);
+            }
+            s += __shfl_xor(s, 1, 64);
+            if (jc < d && h == 0) pr[jc] = th[jc] + s_eff * s;
+            // |Y|^2 for the Hastings term
+            const double yy = (tid < d) ? Y[tid] * Y[tid] : 0.0;
+            const double ys = wave_sum(yy);
+            if ((tid & 63) == 0) sc[8 + (tid >> 6)] = ys;
         }
-        double q = 0.0;
-        for (int k = 0; k < d; ++k) q += Y[k] * Y[k];
         const double logA = sc[0];
         __syncthreads();
+        if constexpr (SPLIT) q = (sc[8] + sc[9]) + (sc[10] + sc[11]);
 
         // ---- target and Metropolis-Hastings log ratio (:157-171) --------------------------------------
         const double t_prop = target(pr);

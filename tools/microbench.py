@@ -181,3 +181,9 @@ if __name__ == "__main__" and "c1" in sys.argv:
 if __name__ == "__main__" and "gibbs_mid" in sys.argv:  # crossover between the lane kernel (d <= 32) and the wide kernel
     for d in (16, 24, 32, 34, 48, 64, 96):
         gibbs(d, 1 << 18, 40, trace=False)
+
+
+if __name__ == "__main__" and "block_mid" in sys.argv:  # where spreading the per-iteration sums over four waves starts to pay
+    for d in (48, 64, 72, 80, 96):
+        rwm_block(d, 4096, 200)
+        rwm_block_shape(d, 3072, 600)
