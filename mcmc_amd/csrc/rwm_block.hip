@@ -29,6 +29,9 @@
 // updates its tile with at most NT(NT+1)/2 FMAs (a_ik - (a_ji / a_jj) a_jk: the square root is off the
 // critical path); the owners alone take the square root and store the finished row of R to LDS.
 // The step is instruction-bound, so what counts is the number of instructions around the FMAs.
+#include <algorithm>
+#include <type_traits>
+
 #include "common.h"
 #include "philox.h"
 #include "targets.h"
@@ -38,7 +41,13 @@ namespace mcmc {
 constexpr int kBlockThreads = 256;
 __host__ __device__ constexpr int blk(int a, int b) { return b * (b + 1) / 2 + a; } // tile block (a,b), a <= b
 
-// parameter block (doubles): init[d] cov[T] R0[T] root0 tmean[d] H[d*d]
+// parameter block (doubles): init[d] cov[T] R0[T] root0 tmean[d] Hdiag[d] meta[2] ttab[256][2] ptab[256][3] pred[d][2] Hq[TP][256]
+//   cov, R0 = chol(covmat): packed by columns, (r,c) r<=c at c(c+1)/2 + r
+//   The two triangular sums of an iteration -- the target's sum_c v_c sum_{i<c} (H_ic + H_ci) v_i and the proposal's
+//   sum_{k<=c} Y_k R_kc -- are cut into runs of consecutive i (k) of one row (column), at most TP (SP) long, one run
+//   per thread (block_segments): ttab[tid] = (row, first i), ptab[tid] = (column, first k, length), -1 = no run;
+//   pred[c] = (first thread, number of threads) of column c.  Hq[t][tid] is the coefficient of term t of thread
+//   tid's target run, zero beyond its end.  meta = (TP, SP).
 struct BlockLayout {
     int d, T;
     __host__ __device__ explicit BlockLayout(int d_) : d(d_), T(d_ * (d_ + 1) / 2) {}
@@ -47,13 +56,46 @@ struct BlockLayout {
     __host__ __device__ int r0() const { return d + T; }
     __host__ __device__ int root0() const { return d + 2 * T; }
     __host__ __device__ int tmean() const { return d + 2 * T + 1; }
-    __host__ __device__ int H() const { return 2 * d + 2 * T + 1; }
-    __host__ __device__ int total() const { return 2 * d + 2 * T + 1 + d * d; }
-    __host__ __device__ int lds_doubles() const { return T + 5 * d + 16 + 2 * (16 * ((d + 15) / 16) + 2) + 16 + 256; }
+    __host__ __device__ int hdiag() const { return 2 * d + 2 * T + 1; }
+    __host__ __device__ int meta() const { return 3 * d + 2 * T + 1; }
+    __host__ __device__ int ttab() const { return meta() + 2; }
+    __host__ __device__ int ptab() const { return ttab() + 2 * kBlockThreads; }
+    __host__ __device__ int pred() const { return ptab() + 3 * kBlockThreads; }
+    __host__ __device__ int hq() const { return pred() + 2 * d; }
+    __host__ __device__ int total(int TP) const { return hq() + TP * kBlockThreads; }
+    // LDS: R, theta, mean, Y, proposal, v + zero pad, scalars, pivot rows, diag products, per-thread partial sums
+    __host__ __device__ int lds_doubles() const { return T + 5 * d + kVPad + 16 + 2 * (16 * ((d + 15) / 16) + 2) + 16 + kBlockThreads; }
+    static constexpr int kVPad = 64; // zeros after v: a target run may read up to TP + 7 entries past its row's last term
 };
 
+// Cuts rows c = 0..d-1 with len(c) terms each into runs of at most S consecutive terms, S the smallest value that
+// needs no more than kBlockThreads runs.  run r: (row[r], first[r], count[r]); rows appear in order.
+struct BlockSegments {
+    int S = 0;
+    std::vector<int> row, first, count;
+};
+inline BlockSegments block_segments(int d, int extra, int min_run) // len(c) = c + extra (0: strictly below the diagonal, 1: with it)
+{
+    BlockSegments g;
+    for (int S = min_run;; ++S) { // a run shorter than one batch of loads only adds threads, not speed
+        long runs = 0;
+        for (int c = 0; c < d; ++c) runs += (c + extra + S - 1) / S;
+        if (runs <= kBlockThreads) {
+            g.S = S;
+            break;
+        }
+    }
+    for (int c = 0; c < d; ++c)
+        for (int f = 0; f < c + extra; f += g.S) {
+            g.row.push_back(c);
+            g.first.push_back(f);
+            g.count.push_back(std::min(g.S, c + extra - f));
+        }
+    return g;
+}
+
 template <int NT, bool FULL>
-__global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmArgs a, const double *__restrict__ prm)
+__global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) void rwm_block_kernel(const RwmArgs a, const double *__restrict__ prm)
 {
     extern __shared__ double lds[];
     const int d = a.d;
@@ -66,17 +108,12 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
     double *const Y = mn + d;     // proposal normals
     double *const pr = Y + d;     // theta_propose
     double *const v = pr + d;     // scratch: x - mean of the target, residual
-    double *const sc = v + d;     // sc[0] = log(A); sc[4..7], sc[8..11]: per-wave partial sums
+    double *const sc = v + d + BlockLayout::kVPad; // v is followed by zeros; sc[0] = log(A); sc[4..7], sc[8..11]: per-wave partial sums
     double *const raw = sc + 16;  // two unscaled pivot rows (double buffer): 16 NT entries, the pivot, one pad
     constexpr int RS = 16 * NT + 2;
     double *const pp = raw + 2 * RS; // 16 partial products of diag(R)
-    double *const part = pp + 16;    // [2][128] halves of the target's matrix-vector product
+    double *const part = pp + 16;    // per-thread partial sums of the proposal
     constexpr int NB = NT * (NT + 1) / 2;
-    // The matrix-vector products and sums of an iteration are either spread over all four waves (SPLIT) or done
-    // one thread per row with fewer barriers.  Measured, size phase, chain-iterations/s split vs not:
-    // d = 32: 1.59e8 / 1.78e8, d = 48: 1.29e8 / 1.00e8, d = 64: 8.2e7 / 9.6e7 (the split form drops to two waves
-    // per SIMD there), d = 72: 7.1e7 / 5.0e7, d = 100: 6.1e7 / 3.8e7, d = 128: 5.0e7 / 3.2e7.
-    constexpr bool SPLIT = NT >= 5 || NT == 3;
     const int64_t c = blockIdx.x;
     const int64_t n = a.n_chains;
     const uint64_t gchain = (uint64_t)(a.chain_offset + c);
@@ -88,7 +125,13 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
     const bool need_moments = ashs != 0 || (FULL && a.d_sigma_trace) || a.d_final_mean || a.d_final_cov || a.d_state_in || a.d_state_out;
     const int i0 = a.iter_offset; // iterations done before this launch (checkpoint / resume)
     const double *__restrict__ tmean = prm + L.tmean();
-    const double *__restrict__ H = prm + L.H();
+    const double *__restrict__ Hd = prm + L.hdiag();
+    const double *__restrict__ Hq = prm + L.hq();
+    // this thread's runs of the target's and the proposal's triangular sums
+    const int TP = __builtin_amdgcn_readfirstlane((int)prm[L.meta()]), SP = __builtin_amdgcn_readfirstlane((int)prm[L.meta() + 1]);
+    const int t_row = (int)prm[L.ttab() + 2 * tid], t_first = (int)prm[L.ttab() + 2 * tid + 1];
+    const int p_col = (int)prm[L.ptab() + 3 * tid], p_first = (int)prm[L.ptab() + 3 * tid + 1], p_len = (int)prm[L.ptab() + 3 * tid + 2];
+    const int r_first = tid < d ? (int)prm[L.pred() + 2 * tid] : 0, r_count = tid < d ? (int)prm[L.pred() + 2 * tid + 1] : 0;
     const int ti = tid >> 4, tk = tid & 15; // tile row / column: the 16 owners of a row sit in one wave
 
     // covmat_empirical tile (registers) and the working copy the factorization consumes
@@ -101,64 +144,60 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
         th[tid] = x0;
         mn[tid] = x0;
     }
+    if (tid < BlockLayout::kVPad) v[d + tid] = 0.0;
     __syncthreads();
 
-    // sum over the wavefront, every lane gets it
+    // sum over the wavefront, every lane gets it: four DPP steps inside each row of 16 lanes (no LDS round trip, unlike
+    // a shuffle), then the four row totals through scalar registers
     auto wave_sum = [](double x) -> double {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
-        return x;
+        auto dpp_add = [](double y, auto ctrl) -> double {
+            constexpr int C = decltype(ctrl)::value;
+            const uint64_t b = (uint64_t)__double_as_longlong(y);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, C, 0xf, 0xf, false);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), C, 0xf, 0xf, false);
+            return y + __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+        };
+        x = dpp_add(x, std::integral_constant<int, 0xB1>{});  // quad_perm [1,0,3,2]: lane ^ 1
+        x = dpp_add(x, std::integral_constant<int, 0x4E>{});  // quad_perm [2,3,0,1]: lane ^ 2
+        x = dpp_add(x, std::integral_constant<int, 0x141>{}); // row_half_mirror: the other quad of the same half row
+        x = dpp_add(x, std::integral_constant<int, 0x140>{}); // row_mirror: the other half of the row
+        auto row_total = [&](int lane) -> double {
+            const uint64_t b = (uint64_t)__double_as_longlong(x);
+            const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)b, lane), hi = __builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), lane);
+            return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+        };
+        return (row_total(0) + row_total(16)) + (row_total(32) + row_total(48));
     };
-    // -0.5 (x - m)^T H (x - m); result replicated in every thread.  (H v) is formed by all four waves: waves 0-1
-    // sum the columns [0, jm) of their row, waves 2-3 the columns [jm, d), eight coalesced loads in flight each;
-    // the d products v_i (H v)_i are summed by a wave reduction + four partial sums in LDS.  (A 100-step serial
-    // sum replicated in every thread, as in the first version, costs ~11 cycles per step: the iteration is a
-    // chain of such latencies, not of flops.)
+    // -0.5 (x - m)^T H (x - m); result replicated in every thread.  An iteration is a chain of latencies, not of
+    // flops: a wave alone on its SIMD issues one instruction per ~11 cycles (measured with per-phase clocks at
+    // d = 100: 12 instructions and an exposed LDS read per term made this sum 6 000 cycles), so what counts is the
+    // number of instructions per term and per thread.  Each thread owns one run of consecutive terms of one row
+    // (block_segments): its coefficients come coalesced from L2, eight loads in flight, the v entries from LDS at
+    // constant offsets, one FMA per term; one wave reduction plus four partial sums in LDS finish the sum.
     auto target = [&](const double *x) -> double {
         if (tid < d) v[tid] = x[tid] - tmean[tid];
         __syncthreads();
-        if constexpr (!SPLIT) { // small d: one thread per row, left-to-right sums (short chains; fewer barriers win)
-            if (tid < d) {
-                double s = 0.0;
-                int j = 0;
-                for (; j + 8 <= d; j += 8) {
-                    double h[8];
+        double acc = 0.0;
+        if (t_row >= 0) {
+            const double *const vp = v + t_first;
+            const double *const hp = Hq + tid;
+            constexpr int CH = NT <= 4 ? 4 : 8; // loads in flight; small d: short runs, and the registers decide the occupancy
+            for (int t = 0; t < TP; t += CH) {
+                double h[CH], vv[CH];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) h[u] = H[(int64_t)(j + u) * d + tid];
+                for (int u = 0; u < CH; ++u) h[u] = (t + u < TP) ? hp[(t + u) * kBlockThreads] : 0.0;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) s += h[u] * v[j + u];
-                }
-                for (; j < d; ++j) s += H[(int64_t)j * d + tid] * v[j];
-                part[tid] = v[tid] * s;
+                for (int u = 0; u < CH; ++u) vv[u] = vp[t + u]; // past the run: zero coefficient, finite v or the zero pad
+#pragma unroll
+                for (int u = 0; u < CH; ++u) acc = fma(h[u], vv[u], acc);
             }
-            __syncthreads();
-            double q = 0.0;
-            for (int i = 0; i < d; ++i) q += part[i];
-            return -0.5 * q;
-        } else {
-            const int half = tid >> 7, row = tid & 127;
-            if (row < d) {
-                const int jm = (d + 1) >> 1;
-                int j = half ? jm : 0;
-                const int j1 = half ? d : jm;
-                double s = 0.0;
-                for (; j + 8 <= j1; j += 8) {
-                    double h[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) h[u] = H[(int64_t)(j + u) * d + row];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) s = fma(h[u], v[j + u], s);
-                }
-                for (; j < j1; ++j) s = fma(H[(int64_t)j * d + row], v[j], s);
-                part[half * 128 + row] = s;
-            }
-            __syncthreads();
-            const double wv = (tid < d) ? v[tid] * (part[tid] + part[128 + tid]) : 0.0;
-            const double ws = wave_sum(wv);
-            if ((tid & 63) == 0) sc[4 + (tid >> 6)] = ws;
-            __syncthreads();
-            return -0.5 * ((sc[4] + sc[5]) + (sc[6] + sc[7]));
+            acc *= v[t_row];
         }
+        if (tid < d) acc = fma(Hd[tid] * v[tid], v[tid], acc);
+        const double ws = wave_sum(acc);
+        if ((tid & 63) == 0) sc[4 + (tid >> 6)] = ws;
+        __syncthreads();
+        return -0.5 * ((sc[4] + sc[5]) + (sc[6] + sc[7]));
     };
 
     double rootTerm = prm[L.root0()];
@@ -216,13 +255,18 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
         __syncthreads();
     }
 
+    // pow(adapt_size_cooling, i - adapt_size_start), fetched one iteration ahead: the adaptation opens the
+    // iteration and would otherwise wait for an L2 round trip
+    double cool_next = ass != 0 ? a.d_cool_pow[1] : 0.0;
     for (int i = i0 + 1; i <= i0 + a.n_iterations; ++i) {
         const int li = i - i0; // position inside this launch: streams, diagnostics and the cooling table are per launch
         const double di = (double)i;
+        const double cool = cool_next;
+        if (ass != 0 && li < a.n_iterations) cool_next = a.d_cool_pow[li + 1];
         // ---- adaptation of covmat_proposal (adaptMCMC_source.cpp:117-139), replicated ---------------
         bool rescale = false, refactor = false;
         if (ass != 0 && i >= ass && (ashs == 0 || mul_rn(rate, di) < (double)ashs)) {
-            scaling_multiplier = fm_exp(a.d_cool_pow[li] * (rate - 0.234));
+            scaling_multiplier = fm_exp(cool * (rate - 0.234));
             scaling_sd = mul_rn(scaling_sd, scaling_multiplier);
             scaling_sd = (a.max_scaling_sd < scaling_sd) ? a.max_scaling_sd : scaling_sd;
             const double s2 = mul_rn(scaling_sd, scaling_sd);
@@ -322,7 +366,8 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
                 b *= b;
             }
             const double dt = sp * prodR;
-            rootTerm = 1.0 / sqrt(a.twopi_pow_d * (dt * dt));
+            double sq_unused;
+            fm_sqrt_rsq(a.twopi_pow_d * (dt * dt), sq_unused, rootTerm);
         }
 
         // ---- draws: d normals, then one uniform (:149-152,174) ----------------------------------------
@@ -344,36 +389,39 @@ __global__ __launch_bounds__(kBlockThreads, 2) void rwm_block_kernel(const RwmAr
         }
         __syncthreads();
 
-        // ---- proposal theta + Y * R (:153-154) --------------------------------------------------------
-        double q;
-        if constexpr (!SPLIT) { // thread j owns column j
-            if (tid < d) {
-                const double *col = A + tri(0, tid);
-                double s = 0.0;
-                for (int k = 0; k <= tid; ++k) s += Y[k] * col[k];
-                pr[tid] = th[tid] + s_eff * s;
-            }
-            q = 0.0;
-            for (int k = 0; k < d; ++k) q += Y[k] * Y[k];
-        } else { // two threads per column, each half of the k range
-            const int jc = tid >> 1, h = tid & 1;
+        // ---- proposal theta + Y * R (:153-154): one run of consecutive k of one column per thread, then the runs
+        // of a column are added in order by its thread ------------------------------------------------------------
+        {
             double s = 0.0;
-            if (jc < d) {
-                const double *col = A + tri(0, jc);
-                const int m = (jc + 1) >> 1;
-                const int k1 = h ? jc + 1 : m;
-                for (int k = h ? m : 0; k < k1; ++k) s = fma(Y[k], col[k], s);
+            if (p_col >= 0) {
+                const double *const col = A + tri(0, p_col) + p_first;
+                const double *const yp = Y + p_first;
+                for (int u = 0; u < SP; u += 4) { // reads past the run stay inside the workgroup's LDS and are not used
+                    double r[4], y[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        r[q] = col[u + q];
+                        y[q] = yp[u + q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) s = (u + q < p_len) ? fma(y[q], r[q], s) : s;
+                }
             }
-            s += __shfl_xor(s, 1, 64);
-            if (jc < d && h == 0) pr[jc] = th[jc] + s_eff * s;
+            part[tid] = s;
             // |Y|^2 for the Hastings term
             const double yy = (tid < d) ? Y[tid] * Y[tid] : 0.0;
             const double ys = wave_sum(yy);
             if ((tid & 63) == 0) sc[8 + (tid >> 6)] = ys;
+            __syncthreads();
+            if (tid < d) {
+                double t = part[r_first];
+                for (int q = 1; q < r_count; ++q) t += part[r_first + q];
+                pr[tid] = th[tid] + s_eff * t;
+            }
         }
         const double logA = sc[0];
         __syncthreads();
-        if constexpr (SPLIT) q = (sc[8] + sc[9]) + (sc[10] + sc[11]);
+        const double q = (sc[8] + sc[9]) + (sc[10] + sc[11]);
 
         // ---- target and Metropolis-Hastings log ratio (:157-171) --------------------------------------
         const double t_prop = target(pr);
@@ -526,14 +574,41 @@ int launch_rwm_block(const RwmArgs &a, const RwmParams &p, hipStream_t s)
     if (d < 1 || d > kMaxDimRwm) return set_error(MCMC_E_UNSUPPORTED, "adaptive RWM: d=%d outside 1..%d", d, kMaxDimRwm);
     if ((int)p.tparams.size() != d + d * d) return set_error(MCMC_E_BAD_ARG, "gaussian target needs d + d*d parameters");
     const BlockLayout L(d);
-    std::vector<double> blob(L.total(), 0.0);
+    const BlockSegments tseg = block_segments(d, 0, 8), pseg = block_segments(d, 1, 4);
+    const int TP = tseg.S > 0 ? tseg.S : 1, SP = pseg.S;
+    if (TP + 7 > BlockLayout::kVPad + 1) return set_error(MCMC_E_UNSUPPORTED, "adaptive RWM: d=%d needs a longer zero pad", d);
+    std::vector<double> blob(L.total(TP), 0.0);
     for (int k = 0; k < d; ++k) blob[L.init() + k] = p.init[k];
     for (int e = 0; e < L.T; ++e) {
         blob[L.cov() + e] = p.cov_packed[e];
         blob[L.r0() + e] = p.R0_packed[e];
     }
     blob[L.root0()] = 1.0 / std::sqrt(a.twopi_pow_d * p.det0);
-    for (int e = 0; e < d + d * d; ++e) blob[L.tmean() + e] = p.tparams[e];
+    const double *Hm = p.tparams.data() + d; // column-major precision matrix
+    for (int k = 0; k < d; ++k) {
+        blob[L.tmean() + k] = p.tparams[k];
+        blob[L.hdiag() + k] = Hm[(size_t)k * d + k];
+    }
+    blob[L.meta()] = TP;
+    blob[L.meta() + 1] = SP;
+    for (int tid = 0; tid < kBlockThreads; ++tid) {
+        const bool ht = tid < (int)tseg.row.size(), hp = tid < (int)pseg.row.size();
+        blob[L.ttab() + 2 * tid] = ht ? tseg.row[tid] : -1;
+        blob[L.ttab() + 2 * tid + 1] = ht ? tseg.first[tid] : 0;
+        blob[L.ptab() + 3 * tid] = hp ? pseg.row[tid] : -1;
+        blob[L.ptab() + 3 * tid + 1] = hp ? pseg.first[tid] : 0;
+        blob[L.ptab() + 3 * tid + 2] = hp ? pseg.count[tid] : 0;
+        if (ht)
+            for (int t = 0; t < tseg.count[tid]; ++t) {
+                const int row = tseg.row[tid], i = tseg.first[tid] + t;
+                blob[L.hq() + (size_t)t * kBlockThreads + tid] = Hm[(size_t)row * d + i] + Hm[(size_t)i * d + row];
+            }
+    }
+    for (int r = 0; r < (int)pseg.row.size(); ++r) { // runs of a column are consecutive threads
+        const int cl = pseg.row[r];
+        if (blob[L.pred() + 2 * cl + 1] == 0) blob[L.pred() + 2 * cl] = r;
+        blob[L.pred() + 2 * cl + 1] += 1;
+    }
     double *d_prm = nullptr;
     MCMC_HIP_CHECK(hipMallocAsync((void **)&d_prm, blob.size() * sizeof(double), s));
     MCMC_HIP_CHECK(hipMemcpyAsync(d_prm, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, s));
