@@ -159,9 +159,6 @@ def c1_single_chain():
     """BASELINE config C1: adaptMCMC_analysis.R:115-134, ONE chain x 1e5 iterations through the host-pointer
     drop-in call (PCIe-inclusive: upload of parameters, download of theta_trace and the sigma_empirical cube)."""
     import time
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from oracle import oracle as O
-    O.build()
     n = 100000
     tgt = mcmc_amd.Target.goldstein_price()
     for store_sigma in (True, False):
@@ -169,9 +166,6 @@ def c1_single_chain():
         f()
         t0 = time.perf_counter(); r = f(); dt = time.perf_counter() - t0
         print(f"C1 single chain n={n} store_sigma={store_sigma}: GPU drop-in call {dt*1e3:.1f} ms  {n/dt:.3e} iter/s  acceptance {r['acceptance_rate']:.3f}")
-    Z, U = O.stdlib_streams(123.0, n, 2)
-    t0 = time.perf_counter(); ref = O.adaptMCMC(O.goldstein_price_target(), [1.0, 1.0], np.eye(2), n, 100, 0.0, 0, 150, Z, U); dt = time.perf_counter() - t0
-    print(f"C1 single chain n={n}: oracle (1 host thread, C target) {dt*1e3:.1f} ms  {n/dt:.3e} iter/s  acceptance {ref['acceptance_rate']:.3f}")
 
 
 if __name__ == "__main__" and "c1" in sys.argv:
