@@ -330,6 +330,12 @@ int mcmc_chain_moments(const double *d_trace, int32_t n_kept, int32_t burn_kept,
  * sum_c m, sum_c m^2, sum_c s^2 (per coordinate) and the chain count. */
 int mcmc_rhat_partial(const double *d_mean, const double *d_var, int32_t d, int64_t n_chains,
                       double *d_partial, void *stream);
+/* Reduces per-chain theta_mean [d][n_chains] and covmat_empirical [d*d][n_chains] (d_final_mean / d_final_cov of
+ * mcmc_adapt_rwm_batch) to d_partial[2*d*d + d + 1]: sum_c C_c, sum_c m_c m_c^T (both d x d column-major),
+ * sum_c m_c, and the chain count -- the terms of the pooled covariance
+ * mean_c(C_c + m_c m_c^T) - mbar mbar^T over chains of equal length. */
+int mcmc_pooled_cov_partial(const double *d_mean, const double *d_cov, int32_t d, int64_t n_chains,
+                            double *d_partial, void *stream);
 /* Per-chain, per-coordinate effective sample size (Geyer initial positive sequence on the
  * autocorrelation up to max_lag): d_ess is [d][n_chains]. */
 int mcmc_chain_ess(const double *d_trace, int32_t n_kept, int32_t burn_kept, int32_t d,

@@ -116,6 +116,7 @@ SIGNATURES = {
     "mcmc_negSubRow": (C.c_int, [C.c_int32, dp, C.c_int32, dp]),
     "mcmc_chain_moments": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int64, vp, vp, vp]),
     "mcmc_rhat_partial": (C.c_int, [vp, vp, C.c_int32, C.c_int64, vp, vp]),
+    "mcmc_pooled_cov_partial": (C.c_int, [vp, vp, C.c_int32, C.c_int64, vp, vp]),
     "mcmc_chain_ess": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, vp, vp]),
 }
 

@@ -60,6 +60,41 @@ __global__ __launch_bounds__(1024) void rhat_partial_kernel(const double *__rest
     }
 }
 
+// pooled covariance over chains: one 1024-thread block per matrix element (r, cl), fixed-order tree.
+// partial = [sum_c C_c (d*d, column-major), sum_c m_c m_c^T (d*d), sum_c m_c (d), chain count]
+__global__ __launch_bounds__(1024) void pooled_cov_partial_kernel(const double *__restrict__ mean, const double *__restrict__ cov,
+                                                                  int32_t d, int64_t n, double *partial)
+{
+    __shared__ double sm[3][1024];
+    const int e = blockIdx.x, r = e % d, cl = e / d; // element (r, cl) of the column-major d x d matrices
+    const int tid = threadIdx.x;
+    double sc = 0.0, smm = 0.0, s1 = 0.0;
+    for (int64_t c = tid; c < n; c += 1024) {
+        const double mr = mean[(int64_t)r * n + c];
+        sc += cov[(int64_t)e * n + c];
+        smm += mr * mean[(int64_t)cl * n + c];
+        s1 += mr;
+    }
+    sm[0][tid] = sc;
+    sm[1][tid] = smm;
+    sm[2][tid] = s1;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (tid < off) {
+            sm[0][tid] += sm[0][tid + off];
+            sm[1][tid] += sm[1][tid + off];
+            sm[2][tid] += sm[2][tid + off];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        partial[e] = sm[0][0];
+        partial[d * d + e] = sm[1][0];
+        if (cl == 0) partial[2 * d * d + r] = sm[2][0];
+        if (e == 0) partial[2 * d * d + d] = (double)n;
+    }
+}
+
 // Geyer initial-positive-sequence ESS, one thread per (chain, coordinate)
 __global__ __launch_bounds__(256) void chain_ess_kernel(const double *__restrict__ trace, int32_t n_kept, int32_t burn,
                                                         int32_t d, int64_t n, int32_t max_lag, double *ess_out)
@@ -122,6 +157,17 @@ extern "C" int mcmc_rhat_partial(const double *d_mean, const double *d_var, int3
         return set_error(MCMC_E_BAD_ARG, "mcmc_rhat_partial: bad argument");
     hipLaunchKernelGGL(rhat_partial_kernel, dim3((unsigned)d), dim3(1024), 0, (hipStream_t)stream, d_mean, d_var, d,
                        n_chains, d_partial);
+    MCMC_HIP_CHECK(hipGetLastError());
+    return MCMC_OK;
+}
+
+extern "C" int mcmc_pooled_cov_partial(const double *d_mean, const double *d_cov, int32_t d, int64_t n_chains,
+                                       double *d_partial, void *stream)
+{
+    if (!d_mean || !d_cov || !d_partial || d < 1 || n_chains < 1)
+        return set_error(MCMC_E_BAD_ARG, "mcmc_pooled_cov_partial: bad argument");
+    hipLaunchKernelGGL(pooled_cov_partial_kernel, dim3((unsigned)(d * d)), dim3(1024), 0, (hipStream_t)stream, d_mean, d_cov,
+                       d, n_chains, d_partial);
     MCMC_HIP_CHECK(hipGetLastError());
     return MCMC_OK;
 }

@@ -72,3 +72,38 @@ def rhat(mean, var, n_per_chain, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)
     return rhat_from_partial(part, n_per_chain)
+
+
+def pooled_cov_partial(mean, cov):
+    """[d, n_chains] chain means and [d*d, n_chains] chain covariances (final_mean / final_cov of adapt_rwm_batch)
+    -> partial sums [2 d^2 + d + 1] on the device (mcmc_pooled_cov_partial)."""
+    torch = _torch()
+    d, n = mean.shape
+    if tuple(cov.shape) != (d * d, n):
+        raise ValueError("cov must be [d*d, n_chains]")
+    part = torch.empty((2 * d * d + d + 1,), dtype=torch.float64, device=mean.device)
+    check(lib.mcmc_pooled_cov_partial(_dev_ptr(mean), _dev_ptr(cov), d, n, _dev_ptr(part), _stream_ptr()))
+    return part
+
+
+def pooled_cov_from_partial(part):
+    """(all-reduced) partial sums -> pooled mean [d] and covariance [d, d] over all chains (equal lengths)."""
+    p = part.detach().cpu().numpy() if hasattr(part, "detach") else np.asarray(part, dtype=np.float64)
+    d = int(round((-1 + np.sqrt(1 + 8 * (p.size - 1))) / 4))
+    assert 2 * d * d + d + 1 == p.size
+    M = p[-1]
+    sC = p[: d * d].reshape(d, d, order="F")
+    smm = p[d * d: 2 * d * d].reshape(d, d, order="F")
+    mbar = p[2 * d * d: 2 * d * d + d] / M
+    return mbar, (sC + smm) / M - np.outer(mbar, mbar)
+
+
+def pooled_covariance(mean, cov, group=None):
+    """Pooled mean and covariance of the draws of ALL chains of ALL ranks from the per-chain running moments
+    (SURVEY.md section 8e): one device reduction per rank, ONE all-reduce(sum) of 2 d^2 + d + 1 doubles."""
+    import torch.distributed as dist
+
+    part = pooled_cov_partial(mean, cov)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)
+    return pooled_cov_from_partial(part)

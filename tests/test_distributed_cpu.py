@@ -84,3 +84,26 @@ def test_shard_chains_properties():
             assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
     with pytest.raises(ValueError):
         shard_chains(10, 2, 2)
+
+
+def test_pooled_covariance_from_partial_sums_of_two_shards():
+    """pooled covariance from per-chain running moments; the partial sums of two shards add up
+    (the contract of mcmc_pooled_cov_partial reproduced in numpy) to the covariance of all draws pooled."""
+    from mcmc_amd.diagnostics import pooled_cov_from_partial
+
+    rng = np.random.default_rng(7)
+    n, d, total = 150, 4, 11
+    A = rng.standard_normal((d, d))
+    draws = np.einsum("kl,tlc->tkc", A, rng.standard_normal((n, d, total))) + rng.standard_normal((1, d, total))
+    m = draws.mean(0)                                            # [d, chains]
+    Cc = np.einsum("tkc,tlc->klc", draws - m, draws - m) / n     # population covariance per chain, as update_sigma keeps it
+
+    def partial(sl):
+        mm, cc = m[:, sl], Cc[:, :, sl]
+        return np.concatenate([cc.sum(2).ravel(order="F"), np.einsum("kc,lc->kl", mm, mm).ravel(order="F"), mm.sum(1),
+                               [mm.shape[1]]])
+
+    mbar, S = pooled_cov_from_partial(partial(slice(0, 6)) + partial(slice(6, total)))
+    flat = draws.transpose(1, 0, 2).reshape(d, -1)
+    np.testing.assert_allclose(mbar, flat.mean(1), rtol=1e-12)
+    np.testing.assert_allclose(S, np.cov(flat, bias=True), rtol=1e-11, atol=1e-13)

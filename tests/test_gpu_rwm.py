@@ -404,3 +404,18 @@ def test_run_chains_gives_the_list_of_chains_melt_trace_expects(cuda, oracle):
                            U.cpu().numpy()[:, 1], store_sigma=False)
     assert _rel(chains[1]["trace"], ref["theta_trace"]) < RTOL
     assert chains[1]["acceptance_rate"] == ref["acceptance_rate"]
+
+
+def test_pooled_covariance_reducer_matches_the_trace(cuda):
+    """mcmc_pooled_cov_partial on the running moments the sampler keeps (theta_mean, covmat_empirical, :210-214)
+    against the covariance of all stored draws pooled."""
+    import mcmc_amd
+    from mcmc_amd import diagnostics as diag
+
+    d, nc, n = 5, 300, 400
+    Sig, H = _gauss(d, 0.7)
+    out = mcmc_amd.adapt_rwm_batch(mcmc_amd.Target.gaussian(np.ones(d), H), nc, np.zeros(d), np.eye(d), n, 20, 0.0, 0, 60, seed=3)
+    mbar, S = diag.pooled_covariance(out["final_mean"], out["final_cov"])
+    flat = out["theta_trace"].cpu().numpy().transpose(1, 0, 2).reshape(d, -1)
+    np.testing.assert_allclose(mbar, flat.mean(1), rtol=1e-10)
+    np.testing.assert_allclose(S, np.cov(flat, bias=True), rtol=1e-9, atol=1e-12)
