@@ -25,7 +25,8 @@
 
 namespace mcmc {
 
-// parameter block: mu[d] sd[d] lower[d] upper[d] init[d] inv_sd[d] P[d*(d-1)]
+// parameter block: d rows of W = d + 4 doubles -- P_i (d-1 entries), mu_i, sd_i, 1/sd_i, lower_i, upper_i: everything
+// coordinate i needs behind ONE scalar pointer -- then mu[d], init[d]
 template <bool TAIL_SAFE, bool MOMENTS>
 __global__ __launch_bounds__(64, 3) void gibbs_kernel(const GibbsArgs a, const double *__restrict__ prm)
 {
@@ -41,8 +42,8 @@ __global__ __launch_bounds__(64, 3) void gibbs_kernel(const GibbsArgs a, const d
     const bool inject = a.d_U != nullptr;
 
     for (int k = 0; k < d; ++k) {
-        const double x0 = a.d_init ? a.d_init[(int64_t)k * n + cc] : prm[4 * d + k];
-        xc[k * 64 + lane] = x0 - prm[k];
+        const double x0 = a.d_init ? a.d_init[(int64_t)k * n + cc] : prm[(d + 4) * d + d + k];
+        xc[k * 64 + lane] = x0 - prm[(d + 4) * d + k];
         if (MOMENTS && live) {
             a.d_mean[(int64_t)k * n + c] = 0.0;
             a.d_m2[(int64_t)k * n + c] = 0.0;
@@ -53,12 +54,7 @@ __global__ __launch_bounds__(64, 3) void gibbs_kernel(const GibbsArgs a, const d
     for (int j = 1; j <= a.n_sweeps; ++j) {
         int z = 0;
         asm volatile("" : "+s"(z)); // opaque zero: parameter loads stay inside the sweep loop
-        const double *__restrict__ mu = prm + z;
-        const double *__restrict__ sd = mu + d;
-        const double *__restrict__ lower = mu + 2 * d;
-        const double *__restrict__ upper = mu + 3 * d;
-        const double *__restrict__ inv_sd = mu + 5 * d;
-        const double *__restrict__ P = mu + 6 * d;
+        const double *__restrict__ rows = prm + z;
         const int ja = a.sweep_offset + j; // absolute sweep: Philox counter, thinning, status (resume)
         const bool keep = a.d_trace && (ja % a.thin) == 0;
         const int64_t t = ja / a.thin - a.sweep_offset / a.thin - 1;
@@ -74,13 +70,14 @@ __global__ __launch_bounds__(64, 3) void gibbs_kernel(const GibbsArgs a, const d
                 u = (i & 1) ? ub : ua;
             }
             // conditional mean mu_i + P_i (x[-i] - mu[-i])   (tmvrnormGibbs.cpp:124-127)
-            const double *__restrict__ Pi = P + (int64_t)i * (d - 1);
+            const double *__restrict__ Pi = rows + (int64_t)i * (d + 4);
             double s = 0.0;
             for (int k = 0; k < i; ++k) s += Pi[k] * xc[k * 64 + lane];
             for (int k = i + 1; k < d; ++k) s += Pi[k - 1] * xc[k * 64 + lane];
-            const double mu_i = mu[i] + s;
-            const double xi = rtnorm_draw_std<TAIL_SAFE>(u, mu_i, sd[i], inv_sd[i], lower[i], upper[i]);
-            xc[i * 64 + lane] = xi - mu[i];
+            const double mu0 = Pi[d - 1];
+            const double mu_i = mu0 + s;
+            const double xi = rtnorm_draw_std<TAIL_SAFE>(u, mu_i, Pi[d], Pi[d + 1], Pi[d + 2], Pi[d + 3]);
+            xc[i * 64 + lane] = xi - mu0;
             if (!isfinite(xi) && status == MCMC_CHAIN_OK) status = (ja << 4) | MCMC_CHAIN_NONFINITE_STATE;
             if (live) {
                 if (keep) a.d_trace[(t * d + i) * n + c] = xi;
@@ -364,15 +361,18 @@ int launch_gibbs(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipSt
 {
     const int d = a.d;
     if (d < 1 || d > kMaxDimGibbs) return set_error(MCMC_E_UNSUPPORTED, "gibbs: d=%d outside 1..%d", d, kMaxDimGibbs);
-    std::vector<double> blob;
-    blob.reserve((size_t)6 * d + (size_t)d * (d - 1));
-    blob.insert(blob.end(), p.mu.begin(), p.mu.end());
-    blob.insert(blob.end(), p.sd.begin(), p.sd.end());
-    blob.insert(blob.end(), p.lower.begin(), p.lower.end());
-    blob.insert(blob.end(), p.upper.begin(), p.upper.end());
-    blob.insert(blob.end(), p.init.begin(), p.init.end());
-    for (int k = 0; k < d; ++k) blob.push_back(1.0 / p.sd[k]);
-    blob.insert(blob.end(), p.P.begin(), p.P.begin() + (size_t)d * (d - 1));
+    std::vector<double> blob((size_t)(d + 4) * d + 2 * (size_t)d, 0.0);
+    for (int i = 0; i < d; ++i) {
+        double *r = blob.data() + (size_t)i * (d + 4);
+        for (int k = 0; k < d - 1; ++k) r[k] = p.P[(size_t)i * (d - 1) + k];
+        r[d - 1] = p.mu[i];
+        r[d] = p.sd[i];
+        r[d + 1] = 1.0 / p.sd[i];
+        r[d + 2] = p.lower[i];
+        r[d + 3] = p.upper[i];
+        blob[(size_t)(d + 4) * d + i] = p.mu[i];
+        blob[(size_t)(d + 4) * d + d + i] = p.init[i];
+    }
     const bool moments = a.d_mean != nullptr;
     if (d > kGibbsLaneMaxDim) { // wide variant: rows of W doubles, shared by the waves of a workgroup
         const int W = (d + 5 + 1) & ~1;
