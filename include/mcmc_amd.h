@@ -92,12 +92,20 @@ typedef struct mcmc_target {
  *
  *     __device__ double mcmc_user_target(const double (&x)[MCMC_USER_D], const double *params);
  *
- * returning the log-density at x (any non-finite value rejects the proposal, :163-165).
- * MCMC_USER_D (= d) and MCMC_USER_NP (= n_params) are predefined; `params` points at the
- * n_params doubles of mcmc_target::h_params (shared by all chains, resident in LDS); the lean
+ * returning the log-density at x (any non-finite value rejects the proposal, :163-165), for d <= 12
+ * (one chain per lane; `params` = the n_params <= 4096 doubles of mcmc_target::h_params, shared by
+ * all chains, resident in LDS), and for 12 < d <= 128 (one chain per 256-thread workgroup)
+ *
+ *     __device__ double mcmc_user_target_part(const double *x, int d, const double *params,
+ *                                             int part, int nparts);
+ *
+ * returning part `part` of `nparts` of the log-density -- the kernel calls it once per thread and adds
+ * the parts up, so a sum over observations or coordinates is strided by nparts; x is in LDS, `params`
+ * (n_params <= 4 194 304 doubles: room for a data set) in HBM / L2.
+ * MCMC_USER_D (= d) and MCMC_USER_NP (= n_params) are predefined; the lean
  * mcmc::fm_log / fm_exp / fm_sqrt_rsq of csrc/fastmath.h and the usual device math are available.
- * The source is compiled for gfx950 with hipRTC together with the Metropolis kernels (d <= 12:
- * one chain per lane), so the function is inlined into the sampling loop.  Needs the kernel
+ * The source is compiled for gfx950 with hipRTC together with the Metropolis kernels, so the
+ * function is inlined into the sampling loop.  Needs the kernel
  * sources at run time: <library dir>/csrc and <library dir>/../include, or $MCMC_AMD_SRC_DIR,
  * $MCMC_AMD_INCLUDE_DIR; HIP headers from $ROCM_PATH (default /opt/rocm).
  * On a compile error the call returns MCMC_E_BAD_ARG and `log` (capacity log_capacity, may be
@@ -107,7 +115,7 @@ typedef struct mcmc_target {
 int mcmc_target_compile(const char *source, int32_t d, int32_t n_params, void **handle,
                         char *log, int64_t log_capacity);
 int mcmc_target_destroy(void *handle);
-/* log-density of `target` (any kind, d <= 12) at n points: d_x is [d][n], d_out is [n].  Lets a
+/* log-density of `target` at n points (built-in kinds d <= 12, user targets d <= 128): d_x is [d][n], d_out is [n].  Lets a
  * caller check a compiled target against its host definition before sampling.  No counterpart in
  * the reference (there the closure can simply be called from R). */
 int mcmc_target_eval_batch(const mcmc_target *target, int32_t d, int64_t n, const double *d_x,

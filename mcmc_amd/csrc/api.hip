@@ -153,8 +153,8 @@ extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_co
     if (cfg->kernel == MCMC_KERNEL_LANE && d > kMaxLaneDimRwm)
         return set_error(MCMC_E_UNSUPPORTED, "one-chain-per-lane kernel: d=%d above its limit %d", d, kMaxLaneDimRwm);
     const bool use_block = cfg->kernel == MCMC_KERNEL_BLOCK || (cfg->kernel == MCMC_KERNEL_AUTO && d > kMaxLaneDimRwm);
-    if (use_block && target->kind != MCMC_TARGET_GAUSSIAN_PREC)
-        return set_error(MCMC_E_UNSUPPORTED, "the per-workgroup kernel (d > %d) serves the Gaussian target only", kMaxLaneDimRwm);
+    if (use_block && target->kind != MCMC_TARGET_GAUSSIAN_PREC && target->kind != MCMC_TARGET_USER)
+        return set_error(MCMC_E_UNSUPPORTED, "the per-workgroup kernel (d > %d) serves the Gaussian target and user targets only", kMaxLaneDimRwm);
 
     RwmParams p;
     int rc = build_rwm_params(target, d, io->h_init_theta, io->h_covmat, p);

@@ -141,6 +141,8 @@ int launch_init_normal(uint64_t seed, int64_t chain_offset, int64_t n_chains, in
 // rtc.hip: the same two launches for a MCMC_TARGET_USER target
 int launch_rwm_lane_user(const RwmArgs &a, const RwmParams &p, hipStream_t s);
 int launch_rwm_pair_user(const RwmArgs &a, const RwmParams &p, hipStream_t s);
+int launch_rwm_block_user(const RwmArgs &a, const RwmParams &p, hipStream_t s);
+int launch_rwm_block_with(const RwmArgs &a, const RwmParams &p, hipStream_t s, bool user, const RwmLauncher &launch);
 int user_target_param_count(const void *handle, int d);
 #endif
 

@@ -29,12 +29,20 @@
 // updates its tile with at most NT(NT+1)/2 FMAs (a_ik - (a_ji / a_jj) a_jk: the square root is off the
 // critical path); the owners alone take the square root and store the finished row of R to LDS.
 // The step is instruction-bound, so what counts is the number of instructions around the FMAs.
+#ifndef __HIPCC_RTC__
 #include <algorithm>
-#include <type_traits>
+#endif
 
 #include "common.h"
 #include "philox.h"
 #include "targets.h"
+
+// A user target for 12 < d <= 128 exists only inside a run-time compiled module (user_target.hip defines
+// MCMC_USER_BLOCK ahead of this file and appends the user's definition): the log-density as a sum of `nparts`
+// partial terms, one per thread of the chain's workgroup; x is the point (in LDS), the kernel adds the parts up.
+#ifdef MCMC_USER_BLOCK
+__device__ double mcmc_user_target_part(const double *x, int d, const double *params, int part, int nparts);
+#endif
 
 namespace mcmc {
 
@@ -68,6 +76,7 @@ struct BlockLayout {
     static constexpr int kVPad = 64; // zeros after v: a target run may read up to TP + 7 entries past its row's last term
 };
 
+#ifndef __HIPCC_RTC__
 // Cuts rows c = 0..d-1 with len(c) terms each into runs of at most S consecutive terms, S the smallest value that
 // needs no more than kBlockThreads runs.  run r: (row[r], first[r], count[r]); rows appear in order.
 struct BlockSegments {
@@ -93,8 +102,15 @@ inline BlockSegments block_segments(int d, int extra, int min_run) // len(c) = c
         }
     return g;
 }
+#endif
 
-template <int NT, bool FULL>
+template <int V>
+struct DppCtrl {
+    static constexpr int value = V;
+};
+
+// USER: the target is mcmc_user_target_part (run-time compiled module); its parameters take the place of Hq
+template <int NT, bool FULL, bool USER>
 __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) void rwm_block_kernel(const RwmArgs a, const double *__restrict__ prm)
 {
     extern __shared__ double lds[];
@@ -164,10 +180,10 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), C, 0xf, 0xf, false);
             return y + __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
         };
-        x = dpp_add(x, std::integral_constant<int, 0xB1>{});  // quad_perm [1,0,3,2]: lane ^ 1
-        x = dpp_add(x, std::integral_constant<int, 0x4E>{});  // quad_perm [2,3,0,1]: lane ^ 2
-        x = dpp_add(x, std::integral_constant<int, 0x141>{}); // row_half_mirror: the other quad of the same half row
-        x = dpp_add(x, std::integral_constant<int, 0x140>{}); // row_mirror: the other half of the row
+        x = dpp_add(x, DppCtrl<0xB1>{});  // quad_perm [1,0,3,2]: lane ^ 1
+        x = dpp_add(x, DppCtrl<0x4E>{});  // quad_perm [2,3,0,1]: lane ^ 2
+        x = dpp_add(x, DppCtrl<0x141>{}); // row_half_mirror: the other quad of the same half row
+        x = dpp_add(x, DppCtrl<0x140>{}); // row_mirror: the other half of the row
         auto row_total = [&](int lane) -> double {
             const uint64_t b = (uint64_t)__double_as_longlong(x);
             const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)b, lane), hi = __builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), lane);
@@ -182,6 +198,16 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
     // (block_segments): its coefficients come coalesced from L2, eight loads in flight, the v entries from LDS at
     // constant offsets, one FMA per term; one wave reduction plus four partial sums in LDS finish the sum.
     auto target = [&](const double *x) -> double {
+        if constexpr (USER) { // every thread one part of the user's sum; x (theta or the proposal) is complete in LDS
+#ifdef MCMC_USER_BLOCK
+            const double ws = wave_sum(::mcmc_user_target_part(x, d, Hq, tid, kBlockThreads));
+            if ((tid & 63) == 0) sc[4 + (tid >> 6)] = ws;
+            __syncthreads();
+            return (sc[4] + sc[5]) + (sc[6] + sc[7]);
+#else
+            return 0.0;
+#endif
+        }
         if (tid < d) v[tid] = x[tid] - tmean[tid];
         __syncthreads();
         double acc = 0.0;
@@ -573,29 +599,49 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
     }
 }
 
-int launch_rwm_block(const RwmArgs &a, const RwmParams &p, hipStream_t s)
+#ifdef MCMC_USER_BLOCK
+// log-density of the user target at n points, x as [d][n]: one workgroup per point (mcmc_target_eval_batch, d > 12)
+__global__ __launch_bounds__(kBlockThreads) void block_target_eval_kernel(int64_t n, int d, const double *__restrict__ x,
+                                                                           const double *__restrict__ uprm, double *__restrict__ out)
+{
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x;
+    const int64_t c = blockIdx.x;
+    if (tid < d) lds[tid] = x[(int64_t)tid * n + c];
+    __syncthreads();
+    double acc = ::mcmc_user_target_part(lds, d, uprm, tid, kBlockThreads);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((tid & 63) == 0) lds[d + (tid >> 6)] = acc;
+    __syncthreads();
+    if (tid == 0) out[c] = (lds[d] + lds[d + 1]) + (lds[d + 2] + lds[d + 3]);
+}
+#endif
+
+#ifndef __HIPCC_RTC__
+// user == false: the Gaussian target (p.tparams = m[d], H[d*d]); user == true: p.tparams are the user's parameters
+int launch_rwm_block_with(const RwmArgs &a, const RwmParams &p, hipStream_t s, bool user, const RwmLauncher &launch)
 {
     const int d = a.d;
-    if (p.target_kind != MCMC_TARGET_GAUSSIAN_PREC)
-        return set_error(MCMC_E_BAD_ARG, "target kind %d is 2-dimensional; d=%d", p.target_kind, d);
     if (d < 1 || d > kMaxDimRwm) return set_error(MCMC_E_UNSUPPORTED, "adaptive RWM: d=%d outside 1..%d", d, kMaxDimRwm);
-    if ((int)p.tparams.size() != d + d * d) return set_error(MCMC_E_BAD_ARG, "gaussian target needs d + d*d parameters");
+    if (!user && (int)p.tparams.size() != d + d * d) return set_error(MCMC_E_BAD_ARG, "gaussian target needs d + d*d parameters");
     const BlockLayout L(d);
-    const BlockSegments tseg = block_segments(d, 0, 8), pseg = block_segments(d, 1, 4);
+    const BlockSegments tseg = user ? BlockSegments{} : block_segments(d, 0, 8), pseg = block_segments(d, 1, 4);
     const int TP = tseg.S > 0 ? tseg.S : 1, SP = pseg.S;
     if (TP + 7 > BlockLayout::kVPad + 1) return set_error(MCMC_E_UNSUPPORTED, "adaptive RWM: d=%d needs a longer zero pad", d);
-    std::vector<double> blob(L.total(TP), 0.0);
+    std::vector<double> blob(user ? (size_t)L.hq() + p.tparams.size() + 1 : (size_t)L.total(TP), 0.0);
     for (int k = 0; k < d; ++k) blob[L.init() + k] = p.init[k];
     for (int e = 0; e < L.T; ++e) {
         blob[L.cov() + e] = p.cov_packed[e];
         blob[L.r0() + e] = p.R0_packed[e];
     }
     blob[L.root0()] = 1.0 / std::sqrt(a.twopi_pow_d * p.det0);
-    const double *Hm = p.tparams.data() + d; // column-major precision matrix
-    for (int k = 0; k < d; ++k) {
+    const double *Hm = user ? nullptr : p.tparams.data() + d; // column-major precision matrix
+    for (int k = 0; k < d && !user; ++k) {
         blob[L.tmean() + k] = p.tparams[k];
         blob[L.hdiag() + k] = Hm[(size_t)k * d + k];
     }
+    for (size_t e = 0; e < p.tparams.size() && user; ++e) blob[L.hq() + e] = p.tparams[e];
     blob[L.meta()] = TP;
     blob[L.meta() + 1] = SP;
     for (int tid = 0; tid < kBlockThreads; ++tid) {
@@ -623,25 +669,37 @@ int launch_rwm_block(const RwmArgs &a, const RwmParams &p, hipStream_t s)
     const size_t ldsb = (size_t)L.lds_doubles() * sizeof(double);
     const bool full = a.d_Z || a.d_sigma_trace || a.d_accepted || a.d_log_acceptance || a.d_log_A || a.d_scaling_sd ||
                       a.d_scaling_multiplier || a.d_rate_trace;
-    hipError_t e0 = hipSuccess;
-    auto go = [&](auto kern) {
-        e0 = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-        if (e0 == hipSuccess)
-            hipLaunchKernelGGL(kern, dim3((unsigned)a.n_chains), dim3(kBlockThreads), ldsb, s, a, (const double *)d_prm);
-    };
-    switch ((d + 15) / 16) {
-#define MCMC_CASE(NT) \
-    case NT: if (full) go(rwm_block_kernel<NT, true>); else go(rwm_block_kernel<NT, false>); break;
-        MCMC_CASE(1) MCMC_CASE(2) MCMC_CASE(3) MCMC_CASE(4) MCMC_CASE(5) MCMC_CASE(6) MCMC_CASE(7) MCMC_CASE(8)
-#undef MCMC_CASE
-    default: e0 = hipErrorInvalidValue;
-    }
-    hipError_t e1 = hipGetLastError();
+    hipError_t e1 = launch(full ? 1 : 0, (unsigned)a.n_chains, (unsigned)kBlockThreads, ldsb, s, a, d_prm);
     hipError_t e2 = hipFreeAsync(d_prm, s);
-    if (e0 != hipSuccess) return set_error(MCMC_E_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e0));
     if (e1 != hipSuccess) return set_error(MCMC_E_HIP, "rwm_block_kernel launch failed: %s", hipGetErrorString(e1));
     if (e2 != hipSuccess) return set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e2));
     return MCMC_OK;
 }
+
+int launch_rwm_block(const RwmArgs &a, const RwmParams &p, hipStream_t s)
+{
+    if (p.target_kind == MCMC_TARGET_USER) return launch_rwm_block_user(a, p, s);
+    if (p.target_kind != MCMC_TARGET_GAUSSIAN_PREC)
+        return set_error(MCMC_E_BAD_ARG, "target kind %d is 2-dimensional; d=%d", p.target_kind, a.d);
+    const int nt = (a.d + 15) / 16;
+    return launch_rwm_block_with(
+        a, p, s, false,
+        [nt](int full, unsigned grid, unsigned block, size_t ldsb, hipStream_t st, const RwmArgs &aa, const double *d_prm) {
+            auto go = [&](auto kern) {
+                hipError_t e0 = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+                if (e0 != hipSuccess) return e0;
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(block), ldsb, st, aa, d_prm);
+                return hipGetLastError();
+            };
+            switch (nt) {
+#define MCMC_CASE(NT) \
+    case NT: return full ? go(rwm_block_kernel<NT, true, false>) : go(rwm_block_kernel<NT, false, false>);
+                MCMC_CASE(1) MCMC_CASE(2) MCMC_CASE(3) MCMC_CASE(4) MCMC_CASE(5) MCMC_CASE(6) MCMC_CASE(7) MCMC_CASE(8)
+#undef MCMC_CASE
+            default: return hipErrorInvalidValue;
+            }
+        });
+}
+#endif // !__HIPCC_RTC__
 
 } // namespace mcmc

@@ -35,15 +35,16 @@ struct UserModule {
     hipModule_t mod = nullptr;
     hipFunction_t lane[2] = {nullptr, nullptr}; // FULL = false / true
     hipFunction_t pair[3] = {nullptr, nullptr, nullptr}; // no moments / MOMENTS / MOMENTS + STATE
+    hipFunction_t block[2] = {nullptr, nullptr}; // d > 12: FULL = false / true
     hipFunction_t eval = nullptr;
 };
 
 struct UserTarget {
     uint32_t magic = kUserMagic;
     int d = 0, np = 0;
-    bool has_pair = false;
+    bool has_pair = false, is_block = false; // is_block: d > 12, compiled into the per-workgroup kernel
     std::vector<char> code;
-    std::string lane_name[2], pair_name[3], eval_name;
+    std::string lane_name[2], pair_name[3], block_name[2], eval_name;
     std::mutex mu;
     std::map<int, UserModule> per_device; // loaded at first use on each device
 };
@@ -80,7 +81,8 @@ int get_module(UserTarget *u, UserModule **out)
     UserModule &m = u->per_device[dev];
     if (!m.mod) {
         MCMC_HIP_CHECK(hipModuleLoadData(&m.mod, u->code.data()));
-        for (int v = 0; v < 2; ++v) MCMC_HIP_CHECK(hipModuleGetFunction(&m.lane[v], m.mod, u->lane_name[v].c_str()));
+        for (int v = 0; v < 2 && u->is_block; ++v) MCMC_HIP_CHECK(hipModuleGetFunction(&m.block[v], m.mod, u->block_name[v].c_str()));
+        for (int v = 0; v < 2 && !u->is_block; ++v) MCMC_HIP_CHECK(hipModuleGetFunction(&m.lane[v], m.mod, u->lane_name[v].c_str()));
         for (int v = 0; v < 3 && u->has_pair; ++v)
             MCMC_HIP_CHECK(hipModuleGetFunction(&m.pair[v], m.mod, u->pair_name[v].c_str()));
         MCMC_HIP_CHECK(hipModuleGetFunction(&m.eval, m.mod, u->eval_name.c_str()));
@@ -107,10 +109,26 @@ int user_target_param_count(const void *handle, int d)
     return u->np;
 }
 
+int launch_rwm_block_user(const RwmArgs &a, const RwmParams &p, hipStream_t s)
+{
+    UserTarget *u = as_user(p.user);
+    if (!u || u->d != a.d) return set_error(MCMC_E_BAD_ARG, "user target handle missing or compiled for another d");
+    if (!u->is_block)
+        return set_error(MCMC_E_UNSUPPORTED, "this user target was compiled for the one-chain-per-lane kernels (d <= %d)", kMaxLaneDimRwm);
+    UserModule *m = nullptr;
+    const int rc = get_module(u, &m);
+    if (rc != MCMC_OK) return rc;
+    return launch_rwm_block_with(a, p, s, true,
+                                 [m](int full, unsigned grid, unsigned block, size_t ldsb, hipStream_t st, const RwmArgs &aa,
+                                     const double *d_prm) { return module_launch(m->block[full], grid, block, ldsb, st, aa, d_prm); });
+}
+
 int launch_rwm_lane_user(const RwmArgs &a, const RwmParams &p, hipStream_t s)
 {
     UserTarget *u = as_user(p.user);
     if (!u || u->d != a.d) return set_error(MCMC_E_BAD_ARG, "user target handle missing or compiled for another d");
+    if (u->is_block)
+        return set_error(MCMC_E_UNSUPPORTED, "this user target was compiled for the per-workgroup kernel (d > %d)", kMaxLaneDimRwm);
     UserModule *m = nullptr;
     const int rc = get_module(u, &m);
     if (rc != MCMC_OK) return rc;
@@ -150,23 +168,35 @@ extern "C" int mcmc_target_compile(const char *source, int32_t d, int32_t n_para
     if (log && log_capacity > 0) log[0] = 0;
     if (!source || !handle) return set_error(MCMC_E_BAD_ARG, "mcmc_target_compile: NULL argument");
     *handle = nullptr;
-    if (d < 1 || d > kMaxLaneDimRwm)
-        return set_error(MCMC_E_UNSUPPORTED, "user targets run in the one-chain-per-lane kernels: d=%d outside 1..%d", d, kMaxLaneDimRwm);
-    if (n_params < 0 || n_params > 4096) return set_error(MCMC_E_BAD_ARG, "n_params=%d outside 0..4096", n_params);
+    if (d < 1 || d > kMaxDimRwm) return set_error(MCMC_E_UNSUPPORTED, "user targets: d=%d outside 1..%d", d, kMaxDimRwm);
+    const bool is_block = d > kMaxLaneDimRwm;
+    // one chain per lane: the parameters sit in LDS beside the shared block; per workgroup: in HBM / L2 (room for data)
+    const int max_params = is_block ? (1 << 22) : 4096;
+    if (n_params < 0 || n_params > max_params) return set_error(MCMC_E_BAD_ARG, "n_params=%d outside 0..%d", n_params, max_params);
 
+    if (is_block && !std::strstr(source, "mcmc_user_target_part"))
+        return set_error(MCMC_E_BAD_ARG, "d=%d > %d runs one chain per workgroup: the source has to define "
+                         "mcmc_user_target_part(const double *x, int d, const double *params, int part, int nparts)", d, kMaxLaneDimRwm);
+    if (!is_block && !std::strstr(source, "mcmc_user_target"))
+        return set_error(MCMC_E_BAD_ARG, "the source has to define mcmc_user_target(const double (&x)[MCMC_USER_D], const double *params)");
     const std::string libdir = library_dir();
     const std::string srcdir = env_or("MCMC_AMD_SRC_DIR", libdir + "/csrc");
     const std::string incdir = env_or("MCMC_AMD_INCLUDE_DIR", libdir + "/../include");
     const std::string rocm = env_or("ROCM_PATH", "/opt/rocm");
     const bool has_pair = d <= kMaxPairDimRwm;
+    const int nt = (d + 15) / 16;
 
     // the run-time compiler has no <stdint.h>; it keeps its own fixed-width types in a namespace
     std::string tu =
         "typedef signed char int8_t;\ntypedef unsigned char uint8_t;\ntypedef signed int int32_t;\ntypedef unsigned int uint32_t;\n"
         "typedef signed long int64_t;\ntypedef unsigned long uint64_t;\n";
-    tu += "#define MCMC_USER_D " + std::to_string(d) + "\n#define MCMC_USER_NP " + std::to_string(n_params) +
-          "\n#include \"rwm_lane.hip\"\n";
-    if (has_pair) tu += "#include \"rwm_pair.hip\"\n";
+    tu += "#define MCMC_USER_NP " + std::to_string(n_params) + "\n";
+    if (is_block) {
+        tu += "#define MCMC_USER_BLOCK 1\n#define MCMC_USER_D " + std::to_string(d) + "\n#include \"rwm_block.hip\"\n";
+    } else {
+        tu += "#define MCMC_USER_D " + std::to_string(d) + "\n#include \"rwm_lane.hip\"\n";
+        if (has_pair) tu += "#include \"rwm_pair.hip\"\n";
+    }
     tu += "#line 1 \"mcmc_user_target\"\n";
     tu += source;
     tu += "\n";
@@ -178,11 +208,14 @@ extern "C" int mcmc_target_compile(const char *source, int32_t d, int32_t n_para
     up->d = d;
     up->np = n_params;
     up->has_pair = has_pair;
+    up->is_block = is_block;
     const std::string ds = std::to_string(d), ks = std::to_string(MCMC_TARGET_USER);
-    std::string expr_lane[2], expr_pair[3], expr_eval = "mcmc::target_eval_kernel<" + ds + ", " + ks + ">";
+    std::string expr_lane[2], expr_pair[3], expr_block[2];
+    const std::string expr_eval = is_block ? std::string("mcmc::block_target_eval_kernel") : "mcmc::target_eval_kernel<" + ds + ", " + ks + ">";
     for (int v = 0; v < 2; ++v) {
         expr_lane[v] = "mcmc::rwm_lane_kernel<" + ds + ", " + ks + ", " + (v ? "true" : "false") + ">";
-        hiprtcAddNameExpression(prog, expr_lane[v].c_str());
+        expr_block[v] = "mcmc::rwm_block_kernel<" + std::to_string(nt) + ", " + (v ? "true" : "false") + ", true>";
+        hiprtcAddNameExpression(prog, is_block ? expr_block[v].c_str() : expr_lane[v].c_str());
     }
     for (int v = 0; v < 3 && has_pair; ++v) {
         expr_pair[v] = "mcmc::rwm_pair_kernel<" + ds + ", " + ks + ", " + (v ? "true" : "false") + ", " + (v == 2 ? "true" : "false") + ">";
@@ -213,7 +246,10 @@ extern "C" int mcmc_target_compile(const char *source, int32_t d, int32_t n_para
         if (hiprtcGetLoweredName(prog, expr.c_str(), &nm) != HIPRTC_SUCCESS || !nm) ok = false;
         else out = nm;
     };
-    for (int v = 0; v < 2; ++v) lowered(expr_lane[v], up->lane_name[v]);
+    for (int v = 0; v < 2; ++v) {
+        if (is_block) lowered(expr_block[v], up->block_name[v]);
+        else lowered(expr_lane[v], up->lane_name[v]);
+    }
     for (int v = 0; v < 3 && has_pair; ++v) lowered(expr_pair[v], up->pair_name[v]);
     lowered(expr_eval, up->eval_name);
     size_t code_size = 0;
@@ -244,7 +280,10 @@ extern "C" int mcmc_target_eval_batch(const mcmc_target *target, int32_t d, int6
                                       void *stream)
 {
     if (!target || !d_x || !d_out || n < 1) return set_error(MCMC_E_BAD_ARG, "mcmc_target_eval_batch: bad argument");
-    if (d < 1 || d > kMaxLaneDimRwm) return set_error(MCMC_E_UNSUPPORTED, "mcmc_target_eval_batch: d=%d outside 1..%d", d, kMaxLaneDimRwm);
+    const bool wide = d > kMaxLaneDimRwm;
+    if (d < 1 || d > kMaxDimRwm || (wide && target->kind != MCMC_TARGET_USER))
+        return set_error(MCMC_E_UNSUPPORTED, "mcmc_target_eval_batch: built-in targets d <= %d, user targets d <= %d (d=%d)",
+                         kMaxLaneDimRwm, kMaxDimRwm, d);
     hipStream_t s = (hipStream_t)stream;
     int np;
     if (target->kind == MCMC_TARGET_USER) {
@@ -269,10 +308,16 @@ extern "C" int mcmc_target_eval_batch(const mcmc_target *target, int32_t d, int6
         rc = get_module(as_user(target->user), &m);
         if (rc == MCMC_OK) {
             int64_t nn = n;
+            int dd = d;
             const double *x = d_x, *prm = d_prm;
             double *out = d_out;
-            void *params[] = {&nn, &x, &prm, &out};
-            e1 = hipModuleLaunchKernel(m->eval, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, s, params, nullptr);
+            if (wide) { // one workgroup per point
+                void *params[] = {&nn, &dd, &x, &prm, &out};
+                e1 = hipModuleLaunchKernel(m->eval, (unsigned)n, 1, 1, 256, 1, 1, (unsigned)((d + 8) * sizeof(double)), s, params, nullptr);
+            } else {
+                void *params[] = {&nn, &x, &prm, &out};
+                e1 = hipModuleLaunchKernel(m->eval, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, s, params, nullptr);
+            }
         }
     } else if (target->kind == MCMC_TARGET_GOLDSTEIN_PRICE) {
         e1 = eval_builtin<2, MCMC_TARGET_GOLDSTEIN_PRICE>(n, d_x, d_prm, d_out, s);

@@ -184,7 +184,9 @@ __device__ double mcmc_user_target(const double (&x)[MCMC_USER_D], const double 
     assert c.kind == 3 and c.n_params == 1 and c.user == t._user.value
     with pytest.raises(mcmc_amd.McmcError, match="undeclared identifier 'y'"):
         mcmc_amd.Target.compile("__device__ double mcmc_user_target(const double (&x)[MCMC_USER_D], const double *p) { return y; }", 2)
-    with pytest.raises(mcmc_amd.McmcError, match="outside 1..12"):
-        mcmc_amd.Target.compile(src, 13, [2.0])
+    with pytest.raises(mcmc_amd.McmcError, match="mcmc_user_target_part"):
+        mcmc_amd.Target.compile(src, 13, [2.0])  # d > 12 runs per workgroup and needs the per-part form
+    with pytest.raises(mcmc_amd.McmcError, match="outside 1..128"):
+        mcmc_amd.Target.compile(src, 129, [2.0])
     with pytest.raises(ValueError):
         t.with_params([1.0, 2.0])

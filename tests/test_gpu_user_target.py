@@ -206,4 +206,97 @@ def test_user_target_minus_inf_support_boundary_and_errors(cuda, oracle):
     with pytest.raises(mcmc_amd.McmcError, match="undeclared identifier"):
         mcmc_amd.Target.compile("__device__ double mcmc_user_target(const double (&x)[MCMC_USER_D], const double *p) { return y; }", 2)
     with pytest.raises(mcmc_amd.McmcError):
-        mcmc_amd.Target.compile(RIDGE_SRC, 13, [1.0, 5.0, 0.05])
+        mcmc_amd.Target.compile(RIDGE_SRC, 129, [1.0, 5.0, 0.05])
+
+
+# ---- user targets for 12 < d <= 128: one chain per workgroup, the log-density as a sum of per-thread parts ----------
+# Bayesian logistic regression: params = tau, n_obs, X [n_obs][d] row-major, y [n_obs]
+LOGIT_SRC = r"""
+__device__ double mcmc_user_target_part(const double *x, int d, const double *params, int part, int nparts)
+{
+    const double tau = params[0];
+    const int n_obs = (int)params[1];
+    const double *X = params + 2, *y = X + (long)n_obs * d;
+    double s = 0.0;
+    for (int r = part; r < n_obs; r += nparts) {
+        double eta = 0.0;
+        for (int k = 0; k < d; ++k) eta += X[(long)r * d + k] * x[k];
+        const double m = eta > 0 ? eta : 0.0; // y eta - log(1 + exp(eta)), without overflow
+        s += y[r] * eta - (m + log(exp(-m) + exp(eta - m)));
+    }
+    for (int k = part; k < d; k += nparts) s -= 0.5 * tau * x[k] * x[k];
+    return s;
+}
+"""
+
+
+def logit_problem(d, n_obs, seed):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n_obs, d)) / np.sqrt(d)
+    beta = rng.standard_normal(d)
+    y = (rng.random(n_obs) < 1.0 / (1.0 + np.exp(-X @ beta))).astype(np.float64)
+    tau = 0.5
+    prm = np.concatenate([[tau, n_obs], X.ravel(), y])
+
+    def f(x):
+        x = np.asarray(x, dtype=np.float64).reshape(-1)
+        eta = X @ x
+        m = np.maximum(eta, 0.0)
+        return float(np.sum(y * eta - (m + np.log(np.exp(-m) + np.exp(eta - m)))) - 0.5 * tau * np.sum(x * x))
+
+    return prm, f
+
+
+@pytest.mark.parametrize("d,n_obs", [(13, 50), (40, 300), (128, 700)])
+def test_wide_user_target_values_match_the_host_closure(cuda, d, n_obs):
+    import mcmc_amd
+
+    prm, f = logit_problem(d, n_obs, d)
+    tgt = mcmc_amd.Target.compile(LOGIT_SRC, d, prm)
+    x = np.random.default_rng(1).standard_normal((d, 200))
+    got = mcmc_amd.target_eval_batch(tgt, cuda.tensor(x, device="cuda")).cpu().numpy()
+    want = np.array([f(x[:, c]) for c in range(x.shape[1])])
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)  # the sum is associated per thread, then over the workgroup
+
+
+@pytest.mark.parametrize("d,ass,ashs,w,win", [(20, 20, 60, 0.0, 0), (48, 15, 0, 0.05, 0)])
+def test_wide_user_target_injected_streams_match_the_oracle_closure(cuda, oracle, d, ass, ashs, w, win):
+    """adaptMCMC_source.cpp:108-216 with target = a closure (oracle) / the same function compiled into the
+    per-workgroup kernel (device).  The log-density sum is associated differently (256 strided parts), so the
+    bar is the contract's: decisions equal unless the margin is below 1e-12, trajectories within 1e-12."""
+    import mcmc_amd
+
+    prm, f = logit_problem(d, 120, 5)
+    tgt = mcmc_amd.Target.compile(LOGIT_SRC, d, prm)
+    nc, n = 6, 400
+    rng = np.random.default_rng(200 + d)
+    init = 0.1 * rng.standard_normal((d, nc))
+    Z = rng.standard_normal((n, d, nc))
+    U = rng.random((n, nc))
+    cov0 = (0.5 / d) * np.eye(d)
+    out = mcmc_amd.adapt_rwm_batch(tgt, nc, cuda.tensor(init, device="cuda"), cov0, n, ass, w, win, ashs,
+                                   Z=cuda.tensor(Z, device="cuda"), U=cuda.tensor(U, device="cuda"), diagnostics=True)
+    cuda.cuda.synchronize()
+    assert np.all(out["status"].cpu().numpy() == 0)
+    tr, acc = out["theta_trace"].cpu().numpy(), out["accepted"].cpu().numpy()
+    ot = oracle.callable_target(f)
+    for c in (0, 5):
+        ref = oracle.adaptMCMC(ot, init[:, c], cov0, n, ass, w, win, ashs, Z[:, :, c], U[:, c], diagnostics=True)
+        diff = np.nonzero(acc[:, c] != ref["diag"]["accepted"])[0]
+        if diff.size:
+            first = diff[0]
+            margin = abs(ref["diag"]["log_A"][first] - ref["diag"]["log_acceptance"][first])
+            assert margin <= 1e-12 * max(1.0, abs(ref["diag"]["pdf_term"][first])), (first, margin)
+            continue
+        assert _rel(tr[:, :, c], ref["theta_trace"]) < RTOL, c
+        assert 0.02 < ref["acceptance_rate"] < 0.95
+    # Philox run: re-sharding and a split run give the same bits
+    kw = dict(seed=9, thin=3)
+    whole = mcmc_amd.adapt_rwm_batch(tgt, 40, np.zeros(d), cov0, 300, ass, w, win, ashs, **kw)
+    part = mcmc_amd.adapt_rwm_batch(tgt, 10, np.zeros(d), cov0, 300, ass, w, win, ashs, chain_offset=30, **kw)
+    assert cuda.equal(whole["theta_trace"][:, :, 30:], part["theta_trace"])
+    a = mcmc_amd.adapt_rwm_batch(tgt, 40, np.zeros(d), cov0, 100, ass, w, win, ashs, checkpoint=True, **kw)
+    b = mcmc_amd.adapt_rwm_batch(tgt, 40, np.zeros(d), cov0, 200, ass, w, win, ashs, resume=a["state"], **kw)
+    assert cuda.equal(cuda.cat([a["theta_trace"], b["theta_trace"]], dim=0), whole["theta_trace"])
+    with pytest.raises(mcmc_amd.McmcError, match="mcmc_user_target_part"):
+        mcmc_amd.Target.compile(RIDGE_SRC, 20, [1.0, 5.0, 0.05])
