@@ -181,3 +181,43 @@ if __name__ == "__main__" and "block_mid" in sys.argv:  # where spreading the pe
     for d in (48, 64, 72, 80, 96):
         rwm_block(d, 4096, 200)
         rwm_block_shape(d, 3072, 600)
+
+
+LOGIT_SRC = r"""
+__device__ double mcmc_user_target_part(const double *x, int d, const double *params, int part, int nparts)
+{
+    const double tau = params[0];
+    const int n_obs = (int)params[1];
+    const double *X = params + 2, *y = X + (long)n_obs * d;
+    double s = 0.0;
+    for (int r = part; r < n_obs; r += nparts) {
+        double eta = 0.0;
+        for (int k = 0; k < d; ++k) eta += X[(long)r * d + k] * x[k];
+        const double m = eta > 0 ? eta : 0.0;
+        s += y[r] * eta - (m + log(exp(-m) + exp(eta - m)));
+    }
+    for (int k = part; k < d; k += nparts) s -= 0.5 * tau * x[k] * x[k];
+    return s;
+}
+"""
+
+
+def rwm_user_wide(d, n_obs, chains, iters):
+    """Bayesian logistic regression (n_obs observations, d coefficients) as a run-time compiled user target in the
+    per-workgroup kernel: 2 n_obs d flops + 2 n_obs transcendental pairs per evaluation"""
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((n_obs, d)) / np.sqrt(d)
+    y = (rng.random(n_obs) < 0.5).astype(np.float64)
+    tgt = mcmc_amd.Target.compile(LOGIT_SRC, d, np.concatenate([[0.5, n_obs], X.ravel(), y]))
+    f = lambda: mcmc_amd.adapt_rwm_batch(tgt, chains, np.zeros(d), (0.5 / d) * np.eye(d), iters, 50, 0.0, 0, 3 * d, seed=1, thin=10,
+                                         final=False)
+    ms = timeit(f, reps=2)
+    out = f()
+    print(f"rwm user target (logistic regression) d={d} n_obs={n_obs} chains={chains} iters={iters}: {ms:.2f} ms  "
+          f"{chains*iters/(ms*1e-3):.3e} chain-iter/s  {chains*iters*n_obs/(ms*1e-3):.3e} likelihood terms/s  "
+          f"acceptance {float(out['acceptance_rate'].mean()):.2f}  shape fraction {float(out['shape_iterations'].double().mean())/iters:.2f}")
+
+
+if __name__ == "__main__" and "user_wide" in sys.argv:
+    rwm_user_wide(40, 1000, 4096, 500)
+    rwm_user_wide(100, 5000, 2048, 200)
