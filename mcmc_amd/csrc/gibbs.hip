@@ -390,7 +390,11 @@ int launch_gibbs(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipSt
         for (int k = 0; k < d; ++k) rows[(size_t)d * W + k] = p.init[k];
         const size_t state = (size_t)d * 64 * sizeof(double), rowb = (size_t)3 * W * sizeof(double);
         int nw = (int)((160 * 1024 - rowb - 4 * 8192) / state); // chain groups per workgroup (slots: at most 8 KB each)
-        nw = nw < 1 ? 1 : (nw > 4 ? 4 : nw);
+        // more than four groups (measured, LDS permitting: d = 34 six groups +14 %, d = 48 five groups -17 %) is no
+        // consistent gain: the per-step barrier spans all waves of the workgroup
+        int nw_cap = 4;
+        if (const char *env = std::getenv("MCMC_GIBBS_GROUPS")) nw_cap = std::atoi(env) > 0 ? std::atoi(env) : 4; // tuning hook
+        nw = nw < 1 ? 1 : (nw > nw_cap ? nw_cap : nw);
         // dot waves per group: nw (1 + ndot) waves per workgroup, at most 16; a function of d only, so that results
         // do not depend on how chains are split over launches
         // (measured at d = 128, two groups: 1 / 2 / 3 / 5 / 7 dot waves -> 507 / 393 / 403 / 522 / 470 ms; beyond two the
