@@ -389,7 +389,8 @@ int launch_gibbs(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipSt
         }
         for (int k = 0; k < d; ++k) rows[(size_t)d * W + k] = p.init[k];
         const size_t state = (size_t)d * 64 * sizeof(double), rowb = (size_t)3 * W * sizeof(double);
-        int nw = (int)((160 * 1024 - rowb - 4 * 8192) / state); // chain groups per workgroup (slots: at most 8 KB each)
+        // chain groups per workgroup: what 160 KB of LDS hold (per group the state and at most 3 KB of hand-over slots)
+        int nw = (int)((160 * 1024 - rowb - 256) / (state + 3072));
         // more than four groups (measured, LDS permitting: d = 34 six groups +14 %, d = 48 five groups -17 %) is no
         // consistent gain: the per-step barrier spans all waves of the workgroup
         int nw_cap = 4;
