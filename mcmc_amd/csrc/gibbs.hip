@@ -312,6 +312,190 @@ __global__ __launch_bounds__(1024) void gibbs_wide_kernel(const GibbsArgs a, con
     }
 }
 
+// Register-state variant for 64 < d <= 128.  In the kernel above the centred state of 64 chains is d x 512 B of LDS
+// (64 KB at d = 128), so a CU holds two chain groups and the draw wave's dependent chain (~4 400 cycles per
+// coordinate) is hidden only twice over.  Here each of the two dot waves of a group keeps ITS 64 coordinates of the
+// state in registers (static indices only: the dot product is 64 unrolled FMAs against broadcast LDS reads of the
+// row, one LDS read per FMA instead of two; a new x_i arrives through a 512-byte LDS slot and is put in place by a
+// select sweep over one eight-register block), the LDS holds only the row ring and the hand-over slots, and a
+// workgroup runs four groups = twelve waves.  The ring rows are written with the two entries the dot waves must not
+// use (the coordinate itself and the one being drawn) zeroed; the latter is kept in an extra slot for the draw wave.
+constexpr int kRegOwn = 64;
+
+template <bool TAIL_SAFE, bool MOMENTS>
+__global__ __launch_bounds__(768) void gibbs_reg_kernel(const GibbsArgs a, const double *__restrict__ rows, int W, int G)
+{
+    extern __shared__ double lds[]; // [3][W + 2] row ring, [G][2][3][64] slots (two partial sums, u), [G][2][64] new x
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool dotter = wave >= G;
+    const int group = dotter ? (wave - G) % G : wave;
+    const int part = dotter ? (wave - G) / G : 0;
+    const int d = a.d;
+    const int W2 = W + 2;
+    const int64_t c = ((int64_t)blockIdx.x * G + group) * 64 + lane;
+    const int64_t n = a.n_chains;
+    const bool live = c < n;
+    const int64_t cc = live ? c : n - 1; // lanes past the end shadow the last chain and store nothing
+    double *const ring = lds;
+    double *const slot = lds + 3 * W2 + (size_t)group * (2 * 3 * 64) + lane;               // [parity][sum0, sum1, u][lane]
+    double *const xnew = lds + 3 * W2 + (size_t)G * (2 * 3 * 64) + (size_t)group * 128 + lane; // [parity][lane]
+    const double *const init = rows + (size_t)d * W;
+    const int64_t total = (int64_t)a.n_sweeps * d;
+    const int base = part * kRegOwn; // first coordinate this dot wave owns
+
+    // ring row for coordinate i: P_i with the entries i (zero already) and prev(i) zeroed, P_i[prev(i)] at [W]
+    auto put_row = [&](double *dst, int i, int e, double val) {
+        const int prev = (i == 0) ? d - 1 : i - 1;
+        if (e == prev) {
+            dst[W] = val;
+            val = 0.0;
+        }
+        dst[e] = val;
+    };
+    for (int e = tid; e < 2 * W; e += nthreads) {
+        const int r = e / W, k = e - r * W;
+        put_row(ring + r * W2, r, k, rows[e]);
+    }
+
+    if (!dotter && MOMENTS && live) {
+        for (int k = 0; k < d; ++k) {
+            a.d_mean[(int64_t)k * n + c] = 0.0;
+            a.d_m2[(int64_t)k * n + c] = 0.0;
+        }
+    }
+    __syncthreads();
+
+    // the ring bookkeeping every wave does in every step: fetch row i+2, and after the step's work put it in place
+    int i = 0, j = 1, r0 = 0; // coordinate, sweep, ring slot of row i
+    auto fetch = [&](int i2, double (&pre)[kWideMaxPrefetch]) {
+#pragma unroll
+        for (int q = 0; q < kWideMaxPrefetch; ++q) {
+            const int e = tid + q * nthreads;
+            pre[q] = (e < W) ? rows[(size_t)i2 * W + e] : 0.0;
+        }
+    };
+    auto store = [&](int i2, int r2, const double (&pre)[kWideMaxPrefetch]) {
+        double *const nxt = ring + r2 * W2;
+#pragma unroll
+        for (int q = 0; q < kWideMaxPrefetch; ++q) {
+            const int e = tid + q * nthreads;
+            if (e < W) put_row(nxt, i2, e, pre[q]);
+        }
+    };
+
+    // ================================ dot waves =====================================================
+    // (a loop of their own: the 128 registers of state must not be live in the draw wave's code)
+    if (dotter) {
+        double x[kRegOwn]; // centred state of coordinates base .. base + 63 (zero beyond d)
+#pragma unroll
+        for (int k = 0; k < kRegOwn; ++k) {
+            const int g = base + k;
+            x[k] = 0.0;
+            if (g < d) x[k] = (a.d_init ? a.d_init[(int64_t)g * n + cc] : init[g]) - rows[(size_t)g * W + d];
+        }
+        double ua = 0.0, ub = 0.0; // the two uniforms of the current Philox block (first dot wave)
+        auto prepare = [&](int ip, int jp, const double *row, int p) {
+            const double *const rp = row + base; // entries past d are the row's scalars: finite, and x is zero there
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < kRegOwn; k += 2) {
+                s0 = fma(rp[k], x[k], s0);
+                s1 = fma(rp[k + 1], x[k + 1], s1);
+            }
+            slot[(p * 3 + part) * 64] = s0 + s1;
+            if (part != 0) return;
+            double u;
+            if (a.d_U) {
+                u = a.d_U[((int64_t)(jp - 1) * d + ip) * n + cc];
+            } else {
+                if ((ip & 1) == 0)
+                    philox_uniform2(PhiloxKey(a.seed), (uint64_t)(a.chain_offset + cc), (uint32_t)(a.sweep_offset + jp), TAG_GIBBS, (uint32_t)(ip >> 1), ua, ub);
+                u = (ip & 1) ? ub : ua;
+            }
+            slot[(p * 3 + 2) * 64] = u;
+        };
+        prepare(0, 1, ring, 0);
+        lds_barrier();
+        for (int64_t t = 0; t < total; ++t) {
+            const int r1 = (r0 == 2) ? 0 : r0 + 1, r2 = (r1 == 2) ? 0 : r1 + 1;
+            const int i1 = (i + 1 == d) ? 0 : i + 1, i2 = (i1 + 1 == d) ? 0 : i1 + 1;
+            const int p = (int)(t & 1);
+            double pre[kWideMaxPrefetch];
+            fetch(i2, pre);
+            if (t > 0) { // x of the coordinate drawn in the previous step goes into its register
+                const int il = ((i == 0) ? d - 1 : i - 1) - base;
+                if (il >= 0 && il < kRegOwn) {
+                    const double v = xnew[(p ^ 1) * 64];
+#pragma unroll
+                    for (int k = 0; k < kRegOwn; ++k) x[k] = (k == il) ? v : x[k];
+                }
+            }
+            if (t + 1 < total) prepare(i1, i1 == 0 ? j + 1 : j, ring + r1 * W2, p ^ 1);
+            store(i2, r2, pre);
+            lds_barrier();
+            r0 = r1;
+            i = i1;
+            if (i == 0) ++j;
+        }
+        return;
+    }
+
+    // ================================ draw wave =====================================================
+    int32_t status = MCMC_CHAIN_OK;
+    double xprev = (a.d_init ? a.d_init[(int64_t)(d - 1) * n + cc] : init[d - 1]) - rows[(size_t)(d - 1) * W + d]; // centred x of the previous coordinate
+    lds_barrier();
+    for (int64_t t = 0; t < total; ++t) {
+        const int r1 = (r0 == 2) ? 0 : r0 + 1, r2 = (r1 == 2) ? 0 : r1 + 1;
+        const int i1 = (i + 1 == d) ? 0 : i + 1, i2 = (i1 + 1 == d) ? 0 : i1 + 1;
+        const int p = (int)(t & 1);
+        double pre[kWideMaxPrefetch];
+        fetch(i2, pre);
+        {
+            const double *const row = ring + r0 * W2;
+            const int ja = a.sweep_offset + j; // absolute sweep (resume)
+            const bool keep = a.d_trace && (ja % a.thin) == 0;
+            const bool mom = MOMENTS && j > a.burn;
+            // conditional mean mu_i + P_i (x[-i] - mu[-i])   (tmvrnormGibbs.cpp:124-127)
+            double s = slot[(p * 3) * 64] + slot[(p * 3 + 1) * 64];
+            s += row[W] * xprev;
+            const double u = slot[(p * 3 + 2) * 64];
+            const double mui = row[d];
+            const double xi = rtnorm_draw_std<TAIL_SAFE>(u, mui + s, row[d + 1], row[d + 2], row[d + 3], row[d + 4]);
+            xprev = xi - mui;
+            xnew[p * 64] = xprev;
+            if (!isfinite(xi) && status == MCMC_CHAIN_OK) status = (ja << 4) | MCMC_CHAIN_NONFINITE_STATE;
+            if (live) {
+                if (keep) a.d_trace[((int64_t)(ja / a.thin - a.sweep_offset / a.thin - 1) * d + i) * n + c] = xi;
+                if (j == a.n_sweeps && a.d_final) a.d_final[(int64_t)i * n + c] = xi;
+                if (mom) {
+                    unsafeAtomicAdd(a.d_mean + (int64_t)i * n + c, xprev);
+                    unsafeAtomicAdd(a.d_m2 + (int64_t)i * n + c, xprev * xprev);
+                }
+            }
+        }
+        store(i2, r2, pre);
+        lds_barrier();
+        r0 = r1;
+        i = i1;
+        if (i == 0) ++j;
+    }
+    if (live) {
+        if (a.d_status) a.d_status[c] = status;
+        if (MOMENTS) {
+            __threadfence();
+            const int nm = a.n_sweeps - a.burn;
+            const double inv = nm > 0 ? 1.0 / (double)nm : 0.0;
+            for (int k = 0; k < d; ++k) {
+                const double s1 = a.d_mean[(int64_t)k * n + c], s2 = a.d_m2[(int64_t)k * n + c];
+                a.d_mean[(int64_t)k * n + c] = rows[(size_t)k * W + d] + s1 * inv;
+                a.d_m2[(int64_t)k * n + c] = fma(-s1 * inv, s1, s2);
+            }
+        }
+    }
+}
+
 // uniforms a Philox Gibbs run draws, [n_sweeps][d][n_chains]
 __global__ __launch_bounds__(256) void gibbs_streams_kernel(uint64_t seed, int64_t chain_offset, int64_t n,
                                                             int32_t n_sweeps, int32_t d, double *U)
@@ -388,6 +572,28 @@ int launch_gibbs(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipSt
             r[d + 4] = p.upper[i];
         }
         for (int k = 0; k < d; ++k) rows[(size_t)d * W + k] = p.init[k];
+        if (d > 64 && d <= 2 * kRegOwn && !std::getenv("MCMC_GIBBS_NO_REG")) { // state in the dot waves' registers
+            const int G = 4;
+            const size_t ldsr = ((size_t)3 * (W + 2) + (size_t)G * (2 * 3 * 64 + 128)) * sizeof(double);
+            double *d_rows = nullptr;
+            MCMC_HIP_CHECK(hipMallocAsync((void **)&d_rows, rows.size() * sizeof(double), s));
+            MCMC_HIP_CHECK(hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, s));
+            MCMC_HIP_CHECK(hipStreamSynchronize(s)); // rows is a local: do not let the copy outlive it
+            const int64_t gridr = (a.n_chains + 64 * G - 1) / (64 * G);
+            auto gor = [&](auto kern) -> int {
+                hipLaunchKernelGGL(kern, dim3((unsigned)gridr), dim3(G * 3 * 64), ldsr, s, a, (const double *)d_rows, W, G);
+                MCMC_HIP_CHECK(hipGetLastError());
+                return MCMC_OK;
+            };
+            int rcr;
+            if (tail_safe)
+                rcr = moments ? gor(gibbs_reg_kernel<true, true>) : gor(gibbs_reg_kernel<true, false>);
+            else
+                rcr = moments ? gor(gibbs_reg_kernel<false, true>) : gor(gibbs_reg_kernel<false, false>);
+            hipError_t er = hipFreeAsync(d_rows, s);
+            if (rcr == MCMC_OK && er != hipSuccess) rcr = set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(er));
+            return rcr;
+        }
         const size_t state = (size_t)d * 64 * sizeof(double), rowb = (size_t)3 * W * sizeof(double);
         // chain groups per workgroup: what 160 KB of LDS hold (per group the state and at most 3 KB of hand-over slots)
         int nw = (int)((160 * 1024 - rowb - 256) / (state + 3072));

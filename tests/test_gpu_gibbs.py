@@ -117,7 +117,7 @@ def test_batch_lane_kernel_injected(cuda, oracle, d, n_chains, n_sweeps):
         np.testing.assert_allclose(out["m2"].cpu().numpy()[:, c], ((want - want.mean(0)) ** 2).sum(0), rtol=1e-10)
 
 
-@pytest.mark.parametrize("d,n_chains,n_sweeps", [(24, 100, 60), (33, 300, 20), (64, 130, 15), (128, 70, 12), (200, 65, 5)])
+@pytest.mark.parametrize("d,n_chains,n_sweeps", [(24, 100, 60), (33, 300, 20), (64, 130, 15), (65, 70, 12), (100, 130, 10), (128, 70, 12), (200, 65, 5)])
 def test_batch_lds_kernel_injected(cuda, oracle, d, n_chains, n_sweeps):
     import mcmc_amd
 
