@@ -312,7 +312,7 @@ __global__ __launch_bounds__(1024) void gibbs_wide_kernel(const GibbsArgs a, con
     }
 }
 
-// Register-state variant for 64 < d <= 128.  In the kernel above the centred state of 64 chains is d x 512 B of LDS
+// Register-state variant for 64 < d <= 256 (two dot waves per group up to d = 128, four above).  In the kernel above the centred state of 64 chains is d x 512 B of LDS
 // (64 KB at d = 128), so a CU holds two chain groups and the draw wave's dependent chain (~4 400 cycles per
 // coordinate) is hidden only twice over.  Here each of the two dot waves of a group keeps ITS 64 coordinates of the
 // state in registers (static indices only: the dot product is 64 unrolled FMAs against broadcast LDS reads of the
@@ -323,9 +323,10 @@ __global__ __launch_bounds__(1024) void gibbs_wide_kernel(const GibbsArgs a, con
 constexpr int kRegOwn = 64;
 
 template <bool TAIL_SAFE, bool MOMENTS>
-__global__ __launch_bounds__(768) void gibbs_reg_kernel(const GibbsArgs a, const double *__restrict__ rows, int W, int G)
+__global__ __launch_bounds__(768) void gibbs_reg_kernel(const GibbsArgs a, const double *__restrict__ rows, int W, int G, int NDW)
 {
-    extern __shared__ double lds[]; // [3][W + 2] row ring, [G][2][3][64] slots (two partial sums, u), [G][2][64] new x
+    extern __shared__ double lds[]; // [3][W + 2] row ring, [G][2][NDW + 1][64] slots (partial sums, u), [G][2][64] new x
+    const int NS = NDW + 1;
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -339,8 +340,8 @@ __global__ __launch_bounds__(768) void gibbs_reg_kernel(const GibbsArgs a, const
     const bool live = c < n;
     const int64_t cc = live ? c : n - 1; // lanes past the end shadow the last chain and store nothing
     double *const ring = lds;
-    double *const slot = lds + 3 * W2 + (size_t)group * (2 * 3 * 64) + lane;               // [parity][sum0, sum1, u][lane]
-    double *const xnew = lds + 3 * W2 + (size_t)G * (2 * 3 * 64) + (size_t)group * 128 + lane; // [parity][lane]
+    double *const slot = lds + 3 * W2 + (size_t)group * (2 * NS * 64) + lane;               // [parity][sums.., u][lane]
+    double *const xnew = lds + 3 * W2 + (size_t)G * (2 * NS * 64) + (size_t)group * 128 + lane; // [parity][lane]
     const double *const init = rows + (size_t)d * W;
     const int64_t total = (int64_t)a.n_sweeps * d;
     const int base = part * kRegOwn; // first coordinate this dot wave owns
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(768) void gibbs_reg_kernel(const GibbsArgs a, const
                 s0 = fma(rp[k], x[k], s0);
                 s1 = fma(rp[k + 1], x[k + 1], s1);
             }
-            slot[(p * 3 + part) * 64] = s0 + s1;
+            slot[(p * NS + part) * 64] = s0 + s1;
             if (part != 0) return;
             double u;
             if (a.d_U) {
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(768) void gibbs_reg_kernel(const GibbsArgs a, const
                     philox_uniform2(PhiloxKey(a.seed), (uint64_t)(a.chain_offset + cc), (uint32_t)(a.sweep_offset + jp), TAG_GIBBS, (uint32_t)(ip >> 1), ua, ub);
                 u = (ip & 1) ? ub : ua;
             }
-            slot[(p * 3 + 2) * 64] = u;
+            slot[(p * NS + NDW) * 64] = u;
         };
         prepare(0, 1, ring, 0);
         lds_barrier();
@@ -458,9 +459,10 @@ __global__ __launch_bounds__(768) void gibbs_reg_kernel(const GibbsArgs a, const
             const bool keep = a.d_trace && (ja % a.thin) == 0;
             const bool mom = MOMENTS && j > a.burn;
             // conditional mean mu_i + P_i (x[-i] - mu[-i])   (tmvrnormGibbs.cpp:124-127)
-            double s = slot[(p * 3) * 64] + slot[(p * 3 + 1) * 64];
+            double s = slot[(p * NS) * 64];
+            for (int q = 1; q < NDW; ++q) s += slot[(p * NS + q) * 64];
             s += row[W] * xprev;
-            const double u = slot[(p * 3 + 2) * 64];
+            const double u = slot[(p * NS + NDW) * 64];
             const double mui = row[d];
             const double xi = rtnorm_draw_std<TAIL_SAFE>(u, mui + s, row[d + 1], row[d + 2], row[d + 3], row[d + 4]);
             xprev = xi - mui;
@@ -572,16 +574,17 @@ int launch_gibbs(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipSt
             r[d + 4] = p.upper[i];
         }
         for (int k = 0; k < d; ++k) rows[(size_t)d * W + k] = p.init[k];
-        if (d > 64 && d <= 2 * kRegOwn && !std::getenv("MCMC_GIBBS_NO_REG")) { // state in the dot waves' registers
-            const int G = 4;
-            const size_t ldsr = ((size_t)3 * (W + 2) + (size_t)G * (2 * 3 * 64 + 128)) * sizeof(double);
+        if (d > 64 && !std::getenv("MCMC_GIBBS_NO_REG")) { // state in the dot waves' registers, 64 coordinates each
+            const int NDW = d <= 2 * kRegOwn ? 2 : 4; // dot waves per group; functions of d only
+            const int G = NDW == 2 ? 4 : 2;           // groups per workgroup: 12 / 10 waves, three per SIMD at most
+            const size_t ldsr = ((size_t)3 * (W + 2) + (size_t)G * (2 * (NDW + 1) * 64 + 128)) * sizeof(double);
             double *d_rows = nullptr;
             MCMC_HIP_CHECK(hipMallocAsync((void **)&d_rows, rows.size() * sizeof(double), s));
             MCMC_HIP_CHECK(hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, s));
             MCMC_HIP_CHECK(hipStreamSynchronize(s)); // rows is a local: do not let the copy outlive it
             const int64_t gridr = (a.n_chains + 64 * G - 1) / (64 * G);
             auto gor = [&](auto kern) -> int {
-                hipLaunchKernelGGL(kern, dim3((unsigned)gridr), dim3(G * 3 * 64), ldsr, s, a, (const double *)d_rows, W, G);
+                hipLaunchKernelGGL(kern, dim3((unsigned)gridr), dim3(G * (1 + NDW) * 64), ldsr, s, a, (const double *)d_rows, W, G, NDW);
                 MCMC_HIP_CHECK(hipGetLastError());
                 return MCMC_OK;
             };

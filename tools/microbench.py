@@ -221,3 +221,8 @@ def rwm_user_wide(d, n_obs, chains, iters):
 if __name__ == "__main__" and "user_wide" in sys.argv:
     rwm_user_wide(40, 1000, 4096, 500)
     rwm_user_wide(100, 5000, 2048, 200)
+
+
+if __name__ == "__main__" and "gibbs_big" in sys.argv:  # 128 < d <= 256: register-state kernel with four dot waves per group
+    for d in (160, 200, 256):
+        gibbs(d, 1 << 16, 10, trace=False)
