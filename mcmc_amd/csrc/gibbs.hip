@@ -321,6 +321,10 @@ __global__ __launch_bounds__(1024) void gibbs_wide_kernel(const GibbsArgs a, con
 // workgroup runs four groups = twelve waves.  The ring rows are written with the two entries the dot waves must not
 // use (the coordinate itself and the one being drawn) zeroed; the latter is kept in an extra slot for the draw wave.
 constexpr int kRegOwn = 64;
+template <int Q>
+struct DotPos {
+    static constexpr int value = Q;
+};
 
 template <bool TAIL_SAFE, bool MOMENTS>
 __global__ __launch_bounds__(768) void gibbs_reg_kernel(const GibbsArgs a, const double *__restrict__ rows, int W, int G, int NDW)
@@ -419,18 +423,30 @@ __global__ __launch_bounds__(768) void gibbs_reg_kernel(const GibbsArgs a, const
         };
         prepare(0, 1, ring, 0);
         lds_barrier();
-        for (int64_t t = 0; t < total; ++t) {
+        // One step: fetch row i+2, put the x drawn in the previous step into its register, prepare coordinate i+1.
+        // The coordinate loop is unrolled by eight so that the position of that x inside its block of eight registers
+        // is a compile-time constant QP: eight selects (one per block) instead of a sweep over all 64 registers.
+        int64_t t = 0;
+        auto step = [&](auto qc) {
+            constexpr int Q = decltype(qc)::value;
             const int r1 = (r0 == 2) ? 0 : r0 + 1, r2 = (r1 == 2) ? 0 : r1 + 1;
             const int i1 = (i + 1 == d) ? 0 : i + 1, i2 = (i1 + 1 == d) ? 0 : i1 + 1;
             const int p = (int)(t & 1);
             double pre[kWideMaxPrefetch];
             fetch(i2, pre);
-            if (t > 0) { // x of the coordinate drawn in the previous step goes into its register
+            if (t > 0) {
                 const int il = ((i == 0) ? d - 1 : i - 1) - base;
                 if (il >= 0 && il < kRegOwn) {
                     const double v = xnew[(p ^ 1) * 64];
+                    if (i == 0) { // the wrap: position (d - 1) % 8 is not known at compile time
 #pragma unroll
-                    for (int k = 0; k < kRegOwn; ++k) x[k] = (k == il) ? v : x[k];
+                        for (int k = 0; k < kRegOwn; ++k) x[k] = (k == il) ? v : x[k];
+                    } else {
+                        constexpr int QP = (Q + 7) & 7; // (i - 1) % 8
+                        const int B = il >> 3;
+#pragma unroll
+                        for (int bq = 0; bq < kRegOwn / 8; ++bq) x[8 * bq + QP] = (bq == B) ? v : x[8 * bq + QP];
+                    }
                 }
             }
             if (t + 1 < total) prepare(i1, i1 == 0 ? j + 1 : j, ring + r1 * W2, p ^ 1);
@@ -439,6 +455,19 @@ __global__ __launch_bounds__(768) void gibbs_reg_kernel(const GibbsArgs a, const
             r0 = r1;
             i = i1;
             if (i == 0) ++j;
+            ++t;
+        };
+        for (int js = 0; js < a.n_sweeps; ++js) {
+            for (int ib = 0; ib < d; ib += 8) { // i == ib + Q inside the unrolled body
+                step(DotPos<0>{});
+                if (ib + 1 < d) step(DotPos<1>{});
+                if (ib + 2 < d) step(DotPos<2>{});
+                if (ib + 3 < d) step(DotPos<3>{});
+                if (ib + 4 < d) step(DotPos<4>{});
+                if (ib + 5 < d) step(DotPos<5>{});
+                if (ib + 6 < d) step(DotPos<6>{});
+                if (ib + 7 < d) step(DotPos<7>{});
+            }
         }
         return;
     }
