@@ -296,7 +296,7 @@ def main():
         else:
             flops_launch = units * gibbs_flops_per_sweep(d)
             kept = n_iter // thin if want_trace else 0
-            kernel = "gibbs_kernel" if d <= 32 else ("gibbs_wide_kernel" if d <= 64 else "gibbs_reg_kernel")
+            kernel = "gibbs_kernel" if d <= 27 else "gibbs_reg_kernel"
             per_unit = {"flops_per_chain_sweep": gibbs_flops_per_sweep(d)}
             unit = "chain-sweeps/s"
             metric = "chain-iterations/sec (TMVN Gibbs sweeps, whole job)"

@@ -23,8 +23,9 @@ constexpr int kMaxLaneDimRwm = 12;
 constexpr int kMaxPairDimRwm = 10;
 // largest d of the LDS-resident kernels (one 64-lane workgroup must fit 160 KiB of LDS)
 constexpr int kMaxDimGibbs = 256;
-// above this d the Gibbs regression rows are staged through LDS by the workgroup (wide variant)
-constexpr int kGibbsLaneMaxDim = 32;
+// above this d the Gibbs sampler runs draw / dot wavefront groups (measured crossover: d = 24 one chain per lane
+// 1.79e9 against 1.66e9 chain-sweeps/s, d = 28 1.40e9 against 1.43e9, d = 32 1.10e9 against 1.26e9)
+constexpr int kGibbsLaneMaxDim = 27;
 constexpr int kMaxDimRwm = 128;
 
 #ifndef __HIPCC_RTC__

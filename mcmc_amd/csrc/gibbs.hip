@@ -312,7 +312,7 @@ __global__ __launch_bounds__(1024) void gibbs_wide_kernel(const GibbsArgs a, con
     }
 }
 
-// Register-state variant for 64 < d <= 256 (two dot waves per group up to d = 128, four above).  In the kernel above the centred state of 64 chains is d x 512 B of LDS
+// Register-state variant, the one that runs for d > 27 (one dot wave per group up to d = 64, two up to 128, four above).  In the kernel above the centred state of 64 chains is d x 512 B of LDS
 // (64 KB at d = 128), so a CU holds two chain groups and the draw wave's dependent chain (~4 400 cycles per
 // coordinate) is hidden only twice over.  Here each of the two dot waves of a group keeps ITS 64 coordinates of the
 // state in registers (static indices only: the dot product is 64 unrolled FMAs against broadcast LDS reads of the
@@ -603,9 +603,10 @@ int launch_gibbs(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipSt
             r[d + 4] = p.upper[i];
         }
         for (int k = 0; k < d; ++k) rows[(size_t)d * W + k] = p.init[k];
-        if (d > 64 && !std::getenv("MCMC_GIBBS_NO_REG")) { // state in the dot waves' registers, 64 coordinates each
-            const int NDW = d <= 2 * kRegOwn ? 2 : 4; // dot waves per group; functions of d only
-            const int G = NDW == 2 ? 4 : 2;           // groups per workgroup: 12 / 10 waves, three per SIMD at most
+        if (!std::getenv("MCMC_GIBBS_NO_REG")) { // state in the dot waves' registers, 64 coordinates each (the LDS-state
+                                                  // kernel below stays for comparison: MCMC_GIBBS_NO_REG=1)
+            const int NDW = d <= kRegOwn ? 1 : (d <= 2 * kRegOwn ? 2 : 4); // dot waves per group; functions of d only
+            const int G = NDW == 1 ? 6 : (NDW == 2 ? 4 : 2);               // groups per workgroup: 12 / 12 / 10 waves, three per SIMD at most
             const size_t ldsr = ((size_t)3 * (W + 2) + (size_t)G * (2 * (NDW + 1) * 64 + 128)) * sizeof(double);
             double *d_rows = nullptr;
             MCMC_HIP_CHECK(hipMallocAsync((void **)&d_rows, rows.size() * sizeof(double), s));

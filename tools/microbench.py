@@ -226,3 +226,8 @@ if __name__ == "__main__" and "user_wide" in sys.argv:
 if __name__ == "__main__" and "gibbs_big" in sys.argv:  # 128 < d <= 256: register-state kernel with four dot waves per group
     for d in (160, 200, 256):
         gibbs(d, 1 << 16, 10, trace=False)
+
+
+if __name__ == "__main__" and "gibbs_cross" in sys.argv:  # lane kernel against the register-state kernel around d = 16..32
+    for d in (20, 24, 28, 32):
+        gibbs(d, 1 << 18, 40, trace=False)
