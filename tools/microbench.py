@@ -231,3 +231,23 @@ if __name__ == "__main__" and "gibbs_big" in sys.argv:  # 128 < d <= 256: regist
 if __name__ == "__main__" and "gibbs_cross" in sys.argv:  # lane kernel against the register-state kernel around d = 16..32
     for d in (20, 24, 28, 32):
         gibbs(d, 1 << 18, 40, trace=False)
+
+
+LOGIT_SRC_T = LOGIT_SRC.replace("X[(long)r * d + k]", "X[(long)k * n_obs + r]")  # X stored [d][n_obs]: consecutive threads, consecutive addresses
+
+
+def rwm_user_wide_t(d, n_obs, chains, iters):
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((n_obs, d)) / np.sqrt(d)
+    y = (rng.random(n_obs) < 0.5).astype(np.float64)
+    tgt = mcmc_amd.Target.compile(LOGIT_SRC_T, d, np.concatenate([[0.5, n_obs], X.T.ravel(), y]))
+    f = lambda: mcmc_amd.adapt_rwm_batch(tgt, chains, np.zeros(d), (0.5 / d) * np.eye(d), iters, 50, 0.0, 0, 3 * d, seed=1, thin=10,
+                                         final=False)
+    ms = timeit(f, reps=2)
+    print(f"rwm user target (logistic regression, X column-major) d={d} n_obs={n_obs} chains={chains} iters={iters}: {ms:.2f} ms  "
+          f"{chains*iters/(ms*1e-3):.3e} chain-iter/s  {chains*iters*n_obs/(ms*1e-3):.3e} likelihood terms/s")
+
+
+if __name__ == "__main__" and "user_wide_t" in sys.argv:
+    rwm_user_wide_t(40, 1000, 4096, 500)
+    rwm_user_wide_t(100, 5000, 2048, 200)
