@@ -18,8 +18,11 @@
  *   - Every call returns MCMC_OK (0) or a negative MCMC_E_* code; mcmc_amd_last_error()
  *     gives the message.  Per-chain failures (what would be a C++ exception inside the
  *     reference's loop) are reported through the d_status / status outputs instead.
- *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Batch calls
- *     are asynchronous on that stream; the single-chain calls synchronise before returning.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  A batch call
+ *     uploads its small shared parameter block on that stream and waits for that copy (the
+ *     host staging buffer is a local), then launches and returns while the kernel runs: the
+ *     sampling itself is asynchronous on `stream`, work queued on it earlier is waited for.
+ *     The single-chain calls synchronise before returning.
  *   - Random numbers: rng_mode MCMC_RNG_PHILOX draws from Philox4x32-10 keyed by `seed` and
  *     counted by (global chain id, iteration, draw), so results do not depend on how chains
  *     are split over launches or GPUs; MCMC_RNG_INJECTED consumes caller-supplied N(0,1) /
