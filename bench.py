@@ -177,9 +177,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one rank per GPU; the modulo only matters when more ranks than GPUs are rehearsed on one box
+    local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("MCMC_BENCH_BACKEND", "nccl")  # "gloo" to rehearse N > 1 on a single GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     wl = args.workload
     defaults = {"c2": (65536, 10000, 5, 1), "c3": (1 << 20, 2000, 3, 1), "c4": (131072, 5000, 1, 0), "c5": (1 << 20, 200, 2, 1)}
