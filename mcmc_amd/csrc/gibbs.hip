@@ -66,7 +66,13 @@ __global__ __launch_bounds__(64, 3) void gibbs_kernel(const GibbsArgs a, const d
             if (inject) {
                 u = a.d_U[((int64_t)(j - 1) * d + i) * n + cc];
             } else {
-                if ((i & 1) == 0) philox_uniform2(key, gchain, (uint32_t)ja, TAG_GIBBS, (uint32_t)(i >> 1), ua, ub);
+                if ((i & 1) == 0) {
+                    // opaque copy of the key: the ten round keys are then formed by scalar adds here; hoisted out of the
+                    // loops they take twenty scalar registers, which spill to VGPR lanes and come back through v_readlane
+                    PhiloxKey kk = key;
+                    asm volatile("" : "+s"(kk.k0), "+s"(kk.k1));
+                    philox_uniform2(kk, gchain, (uint32_t)ja, TAG_GIBBS, (uint32_t)(i >> 1), ua, ub);
+                }
                 u = (i & 1) ? ub : ua;
             }
             // conditional mean mu_i + P_i (x[-i] - mu[-i])   (tmvrnormGibbs.cpp:124-127)

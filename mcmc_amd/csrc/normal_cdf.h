@@ -73,6 +73,14 @@ __device__ __forceinline__ double fma_sc(double a, double b, double c)
     return d;
 }
 
+// a scalar register pair copied to a vector register pair in ONE instruction (the compiler emits two v_mov_b32)
+__device__ __forceinline__ double vreg(double c)
+{
+    double d;
+    asm("v_mov_b64 %0, %1" : "=v"(d) : "s"(c));
+    return d;
+}
+
 // N (a multiple of 8) coefficients of the range starting at `first`, fetched by s_load_dwordx16's not before
 // `after` is known
 template <int N>
@@ -101,7 +109,7 @@ __device__ __forceinline__ double cdf_exp(double x)
     const double kd = rint(xc * t[0]);
     double r = fma(kd, -t[1], xc);
     r = fma(kd, -t[2], r);
-    double p = t[3];
+    double p = vreg(t[3]);
 #pragma unroll
     for (int k = 4; k < 14; ++k) p = fma_sc(p, r, t[k]);
     p = fma(p, r, 0.5);
@@ -123,10 +131,10 @@ __device__ __forceinline__ double cdf_log(double x)
     const double s = f * fm_rcp(2.0 + f);
     const double z = s * s;
     const double w = z * z;
-    double t1 = fma_sc(w, t[1], t[2]);
+    double t1 = fma_sc(w, vreg(t[1]), t[2]);
     t1 = fma_sc(w, t1, t[3]);
     t1 *= w;
-    double t2 = fma_sc(w, t[4], t[5]);
+    double t2 = fma_sc(w, vreg(t[4]), t[5]);
     t2 = fma_sc(w, t2, t[6]);
     t2 = fma_sc(w, t2, t[7]);
     t2 *= z;
@@ -145,7 +153,7 @@ __device__ __forceinline__ double pnorm_std(double x)
     if (y <= 0.67448975) { // for |x| < 1.1e-16 (where R sets both sums to 0) x^2 underflows harmlessly: same value
         const double xsq = x * x;
         const CdfCoef<16> t = cdf_tab<16>(CT_P1, xsq);
-        double xnum = fma_sc(t[0], xsq, t[1]);
+        double xnum = fma_sc(vreg(t[0]), xsq, t[1]);
         xnum = fma_sc(xnum, xsq, t[2]);
         xnum = fma_sc(xnum, xsq, t[3]);
         xnum = fma_sc(xnum, xsq, t[4]);
@@ -158,7 +166,7 @@ __device__ __forceinline__ double pnorm_std(double x)
     double temp;
     if (y <= 5.656854249492380195206754896838) {
         const CdfCoef<24> t = cdf_tab<24>(CT_P2, y);
-        double xnum = fma_sc(t[0], y, t[1]);
+        double xnum = fma_sc(vreg(t[0]), y, t[1]);
 #pragma unroll
         for (int k = 2; k < 9; ++k) xnum = fma_sc(xnum, y, t[k]);
         double xden = y + t[9];
@@ -168,7 +176,7 @@ __device__ __forceinline__ double pnorm_std(double x)
     } else if (-37.5193 < x && x < 8.2924) {
         const double xsq = fm_rcp(x * x);
         const CdfCoef<16> t = cdf_tab<16>(CT_P3, xsq);
-        double xnum = fma_sc(t[0], xsq, t[1]);
+        double xnum = fma_sc(vreg(t[0]), xsq, t[1]);
 #pragma unroll
         for (int k = 2; k < 6; ++k) xnum = fma_sc(xnum, xsq, t[k]);
         double xden = xsq + t[6];
@@ -214,10 +222,10 @@ __device__ __forceinline__ double qnorm_std(double p)
     if (fabs(q) <= 0.425) {
         const double r = .180625 - q * q;
         const CdfCoef<16> t = cdf_tab<16>(CT_Q1, r);
-        double num = fma_sc(t[0], r, t[1]);
+        double num = fma_sc(vreg(t[0]), r, t[1]);
 #pragma unroll
         for (int k = 2; k < 8; ++k) num = fma_sc(num, r, t[k]);
-        double den = fma_sc(t[8], r, t[9]);
+        double den = fma_sc(vreg(t[8]), r, t[9]);
 #pragma unroll
         for (int k = 10; k < 15; ++k) den = fma_sc(den, r, t[k]);
         den = fma(den, r, 1.0);
@@ -229,10 +237,10 @@ __device__ __forceinline__ double qnorm_std(double p)
     if (r <= 5.) {
         r += -1.6;
         const CdfCoef<16> t = cdf_tab<16>(CT_Q2, r);
-        double num = fma_sc(t[0], r, t[1]);
+        double num = fma_sc(vreg(t[0]), r, t[1]);
 #pragma unroll
         for (int k = 2; k < 8; ++k) num = fma_sc(num, r, t[k]);
-        double den = fma_sc(t[8], r, t[9]);
+        double den = fma_sc(vreg(t[8]), r, t[9]);
 #pragma unroll
         for (int k = 10; k < 15; ++k) den = fma_sc(den, r, t[k]);
         den = fma(den, r, 1.0);
@@ -240,10 +248,10 @@ __device__ __forceinline__ double qnorm_std(double p)
     } else {
         r += -5.;
         const CdfCoef<16> t = cdf_tab<16>(CT_Q3, r);
-        double num = fma_sc(t[0], r, t[1]);
+        double num = fma_sc(vreg(t[0]), r, t[1]);
 #pragma unroll
         for (int k = 2; k < 8; ++k) num = fma_sc(num, r, t[k]);
-        double den = fma_sc(t[8], r, t[9]);
+        double den = fma_sc(vreg(t[8]), r, t[9]);
 #pragma unroll
         for (int k = 10; k < 15; ++k) den = fma_sc(den, r, t[k]);
         den = fma(den, r, 1.0);
