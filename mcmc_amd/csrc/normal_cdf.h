@@ -21,7 +21,6 @@ __device__ __forceinline__ double hstep(double acc, double x, double c) { return
 // one (ISA count: 909 scalar against 568 vector instructions, most of them coefficient moves).  Every range
 // starts on a 64-byte boundary.  The pointer goes through an empty asm so that the loads stay inside their
 // branch (hoisted out of the sweep loop they would fill the scalar register file and spill to VGPR lanes).
-#define MCMC_CONST_AS __attribute__((address_space(4)))
 enum CdfTab : int { CT_P1 = 0, CT_P2 = 16, CT_P3 = 40, CT_Q1 = 56, CT_Q2 = 72, CT_Q3 = 88, CT_EXP = 104, CT_LOG = 120, CT_SIZE = 136 };
 static __constant__ __attribute__((aligned(64))) double kCdfTab[CT_SIZE] = {
     // CT_P1: Cody |x| <= 0.67448975, numerator a (5, leading first) then denominator b (4)
@@ -64,41 +63,15 @@ static __constant__ __attribute__((aligned(64))) double kCdfTab[CT_SIZE] = {
     1.479819860511658591e-01, 1.818357216161805012e-01, 2.857142874366239149e-01, 6.666666666666735130e-01,
     6.93147180369123816490e-01, 1.90821492927058770002e-10, 0, 0, 0, 0, 0, 0};
 
-// a * b + c with c read from a scalar register pair.  Written as the instruction itself: left to the compiler,
-// fma(acc, x, <scalar>) becomes two v_mov_b32 plus a v_fmac_f64 whose addend must be a vector register.
-__device__ __forceinline__ double fma_sc(double a, double b, double c)
-{
-    double d;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
-    return d;
-}
-
-// a scalar register pair copied to a vector register pair in ONE instruction (the compiler emits two v_mov_b32)
-__device__ __forceinline__ double vreg(double c)
-{
-    double d;
-    asm("v_mov_b64 %0, %1" : "=v"(d) : "s"(c));
-    return d;
-}
-
-// N (a multiple of 8) coefficients of the range starting at `first`, fetched by s_load_dwordx16's not before
-// `after` is known
+// N (a multiple of 8) coefficients of the range starting at `first`, not before `after` is known
 template <int N>
-struct CdfCoef {
-    typedef double d8 __attribute__((ext_vector_type(8)));
-    d8 v[N / 8];
-    __device__ __forceinline__ double operator[](int k) const { return v[k >> 3][k & 7]; }
-};
+using CdfCoef = ScalarCoef<N>;
 template <int N>
 __device__ __forceinline__ CdfCoef<N> cdf_tab(int first, double after)
 {
-    typedef typename CdfCoef<N>::d8 d8;
-    const MCMC_CONST_AS d8 *t = (const MCMC_CONST_AS d8 *)((const MCMC_CONST_AS double *)kCdfTab + first);
+    const MCMC_CONST_AS double *t = (const MCMC_CONST_AS double *)kCdfTab + first;
     asm volatile("" : "+s"(t) : "v"(after));
-    CdfCoef<N> c;
-#pragma unroll
-    for (int b = 0; b < N / 8; ++b) c.v[b] = t[b];
-    return c;
+    return load_coef<N>(t);
 }
 
 // fm_exp / fm_log<false> of fastmath.h, operation for operation, with the coefficients from the table

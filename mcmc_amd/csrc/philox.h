@@ -120,4 +120,24 @@ __device__ inline void philox_normal2(const PhiloxKey &key, uint64_t chain, uint
     box_muller_bits(r, z0, z1);
 }
 
+// The same two normals with the log and sin/cos coefficients already in scalar registers (fastmath.h: fm_tab)
+__device__ inline void philox_normal2_t(const PhiloxKey &key, uint64_t chain, uint32_t iteration, uint32_t tag,
+                                        uint32_t block, double &z0, double &z1, const ScalarCoef<16> &tl,
+                                        const ScalarCoef<16> &ts)
+{
+    const u32x4 b = philox4x32_10((uint32_t)chain, (uint32_t)(chain >> 32), iteration, (tag << 16) | block,
+                                  key.k0, key.k1);
+    const double u0 = u01_from_bits(b.x, b.y);
+    const double R = fm_sqrt(-2.0 * fm_log_t(u0, tl));
+    const uint32_t k = b.z >> 30;
+    const double f = u01_from_bits(b.z << 2 | b.w >> 30, b.w << 2);
+    double s, c;
+    fm_sincospi_quarter_t(0.5 * f - 0.25, s, c, ts);
+    const double s1 = (k & 1) ? c : s;
+    const double c1 = (k & 1) ? -s : c;
+    const double sg = (k & 2) ? -1.0 : 1.0;
+    z0 = R * (sg * c1);
+    z1 = R * (sg * s1);
+}
+
 } // namespace mcmc

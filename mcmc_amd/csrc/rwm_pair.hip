@@ -254,20 +254,22 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
         for (int i = 1; i <= n_iter + 1 && ok; ++i) { // i: position inside this launch
             double Y[D], eq = 0.0, logA = 0.0;
             if (i <= n_iter) {
+                // log and sin/cos coefficients: one scalar load per iteration serves all Box-Muller pairs and log A
+                const ScalarCoef<16> tl = fm_tab<16>(FT_LOG, i), ts = fm_tab<16>(FT_SINCOS, i);
 #pragma unroll
                 for (int b = 0; 2 * b < D; ++b) {
                     double z0, z1;
-                    philox_normal2(key, gchain, (uint32_t)(i0 + i), TAG_RWM_NORMAL, (uint32_t)b, z0, z1);
+                    philox_normal2_t(key, gchain, (uint32_t)(i0 + i), TAG_RWM_NORMAL, (uint32_t)b, z0, z1, tl, ts);
                     Y[2 * b] = z0;
                     if (2 * b + 1 < D) Y[2 * b + 1] = z1;
                 }
                 double q = 0.0;
 #pragma unroll
                 for (int j = 0; j < D; ++j) q += Y[j] * Y[j];
-                eq = fm_exp(-0.5 * q);
                 double A, u1;
                 philox_uniform2(key, gchain, (uint32_t)(i0 + i), TAG_RWM_UNIFORM, 0u, A, u1);
-                logA = fm_log<false>(A); // A is in the open interval (0,1)
+                logA = fm_log_t(A, tl); // A is in the open interval (0,1)
+                eq = fm_exp_t(-0.5 * q, fm_tab<16>(FT_EXP, i));
             }
             if (i <= n_iter) {
                 if (i > 1) ok = flag_wait(flags, F_READ, i - 1); // the draw buffer is free again
