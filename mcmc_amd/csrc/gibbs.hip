@@ -17,8 +17,6 @@
 //     the loop and then spilling them to VGPR lanes (v_readlane in the hot loop).
 //   * samples: one coalesced store per coordinate and kept sweep, trace[(t*d+k)*n + c] --
 //     512 contiguous bytes per wavefront.
-#include <cstdlib>
-
 #include "common.h"
 #include "normal_cdf.h"
 #include "philox.h"
@@ -103,230 +101,46 @@ __global__ __launch_bounds__(64, 3) void gibbs_kernel(const GibbsArgs a, const d
 }
 
 // ------------------------------------------------------------------------------------------
-// Wide variant for d > 32.  There the regression rows P no longer fit the 16 KB scalar cache (130 KB at
-// d = 128) and the LDS-resident state (64 KB per 64 chains at d = 128) leaves room for two chain groups
+// Wide variant for d > 27.  There the regression rows P no longer fit the 16 KB scalar cache (130 KB at
+// d = 128) and an LDS-resident state (64 KB per 64 chains at d = 128) would leave room for two chain groups
 // per CU: with the kernel above that is two waves on four SIMDs, each exposed to every scalar-load and
 // LDS latency (measured 34 000 cycles per coordinate and wave, 16 times the d = 10 figure).
 //
-// Here a workgroup holds G chain groups and 2 G wavefronts.  Per group a DRAW wave and a DOT wave work
-// one coordinate apart:
+// Here a workgroup holds G chain groups.  Per group a DRAW wave and NDW DOT waves work one coordinate apart:
 //   * while the draw wave turns coordinate i into a sample (2 x pnorm, qnorm: the long dependent
-//     chain), the dot wave forms for coordinate i+1 the conditional-mean sum over every k except i and
+//     chain), the dot waves form for coordinate i+1 the conditional-mean sum over every k except i and
 //     i+1 -- x_i is the only state element that changes meanwhile -- and the uniform u_(i+1), and
-//     leaves both in a double-buffered LDS slot;
+//     leave both in a double-buffered LDS slot;
 //   * the draw wave then adds the one missing term P[i+1][i] x_i (x_i is still in a register).
-// So the d-term dot product is off the critical path, and all four SIMDs of the CU have a wave.
+// So the d-term dot product is off the critical path.
 // The rows are shared by the workgroup: every thread fetches one or two values of row i+2 (P and the
 // five scalars, coalesced) while step i runs and drops them into a three-slot LDS ring before the
 // single barrier that ends the step; the barrier waits for LDS traffic only, so trace and moment
-// stores stay in flight.  Running moments are kept as sums of the centred draw and its square, added to
+// stores stay in flight.  Running moments are kept as sums of the shifted draw and its square, added to
 // HBM with no-return atomics (each lane owns its addresses) and turned into mean / M2 once at the end.
 // The sum is associated differently from the reference's left-to-right loop
 // (tmvrnormGibbs.cpp:124-127): the x_(i-1) term is added last.
 //
 // rows block in HBM: d rows of W doubles: P_i padded to d entries (entry i is 0 and never read), mu_i,
 // sd_i, 1/sd_i, lower_i, upper_i; then init[d].
-// s + sum_{k0 <= k < k1} row[k] * xc[k], row read as same-address (broadcast) LDS loads, xc as [k][lane].
-// Software pipelined by hand: the sixteen LDS loads of the next eight terms are issued before the eight
-// FMAs of the current ones, so a lone wave (this kernel runs one wave per SIMD) does not sit out an LDS
-// round trip per group of terms.
-__device__ __forceinline__ double dot_range(const double *row, const double *xc, int k0, int k1, double s)
-{
-    constexpr int CH = 8;
-    int k = k0;
-    if (k1 - k >= CH) {
-        double ra[CH], xa[CH], rb[CH], xb[CH];
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-            ra[u] = row[k + u];
-            xa[u] = xc[(k + u) * 64];
-        }
-        k += CH;
-        while (k1 - k >= 2 * CH) {
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                rb[u] = row[k + u];
-                xb[u] = xc[(k + u) * 64];
-            }
-#pragma unroll
-            for (int u = 0; u < CH; ++u) s = fma(ra[u], xa[u], s);
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                ra[u] = row[k + CH + u];
-                xa[u] = xc[(k + CH + u) * 64];
-            }
-#pragma unroll
-            for (int u = 0; u < CH; ++u) s = fma(rb[u], xb[u], s);
-            k += 2 * CH;
-        }
-        if (k1 - k >= CH) {
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                rb[u] = row[k + u];
-                xb[u] = xc[(k + u) * 64];
-            }
-#pragma unroll
-            for (int u = 0; u < CH; ++u) s = fma(ra[u], xa[u], s);
-#pragma unroll
-            for (int u = 0; u < CH; ++u) s = fma(rb[u], xb[u], s);
-            k += CH;
-        } else {
-#pragma unroll
-            for (int u = 0; u < CH; ++u) s = fma(ra[u], xa[u], s);
-        }
-    }
-    for (; k < k1; ++k) s = fma(row[k], xc[k * 64], s);
-    return s;
-}
+constexpr int kWideMaxPrefetch = 3; // ceil(W / threads) at d = 256 (two groups of five waves, 640 threads: 1)
 
-constexpr int kWideMaxPrefetch = 3; // ceil(W / threads) at d = 256 (one group, 128 threads)
-
-// G chain groups per workgroup, each with one draw wave (waves 0..G-1) and NDOT dot waves (wave G + part*G + group
-// sums the k-range `part` of the conditional-mean sum).
-template <bool TAIL_SAFE, bool MOMENTS>
-__global__ __launch_bounds__(1024) void gibbs_wide_kernel(const GibbsArgs a, const double *__restrict__ rows, int W, int G, int NDOT)
-{
-    extern __shared__ double lds[]; // [3][W] row ring, [G][2][NDOT+1][64] hand-over slots, then per group the centred state [d][64]
-    const int tid = threadIdx.x, nthreads = blockDim.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool dotter = wave >= G;
-    const int group = dotter ? (wave - G) % G : wave;
-    const int part = dotter ? (wave - G) / G : 0;
-    const int NS = NDOT + 1; // slots per parity: NDOT partial sums, then the uniform
-    const int d = a.d;
-    const int chunk = ((d + NDOT - 1) / NDOT + 7) & ~7;
-    const int ka = part * chunk < d ? part * chunk : d, kb = ka + chunk < d ? ka + chunk : d; // this dot wave's k-range
-    const int64_t c = ((int64_t)blockIdx.x * G + group) * 64 + lane;
-    const int64_t n = a.n_chains;
-    const bool live = c < n;
-    const int64_t cc = live ? c : n - 1; // lanes past the end shadow the last chain and store nothing
-    double *const ring = lds;
-    double *const slot = lds + 3 * W + (size_t)group * (2 * NS * 64) + lane;  // [parity][part sums.., u][lane]
-    double *const xc = lds + 3 * W + (size_t)G * (2 * NS * 64) + (size_t)group * d * 64 + lane; // element k at xc[k * 64]
-    const double *const init = rows + (size_t)d * W;
-    const int64_t total = (int64_t)a.n_sweeps * d; // steps; step t handles coordinate t % d of sweep t / d + 1
-
-    // state, rows 0 and 1
-    if (!dotter) {
-        for (int k = 0; k < d; ++k) {
-            const double x0 = a.d_init ? a.d_init[(int64_t)k * n + cc] : init[k];
-            xc[k * 64] = x0 - rows[(size_t)k * W + d];
-            if (MOMENTS && live) {
-                a.d_mean[(int64_t)k * n + c] = 0.0;
-                a.d_m2[(int64_t)k * n + c] = 0.0;
-            }
-        }
-    }
-    for (int e = tid; e < 2 * W; e += nthreads) ring[e] = rows[e];
-    __syncthreads();
-
-    double ua = 0.0, ub = 0.0; // the two uniforms of the current Philox block (dot wave)
-    // what the dot wave leaves for coordinate i of sweep j in slot parity p
-    auto prepare = [&](int i, int j, const double *row, int p) {
-        const int skip = (i == 0) ? d - 1 : i - 1; // the element the draw wave is still changing
-        const int lo = skip < i ? skip : i, hi = skip < i ? i : skip; // d >= 3: two distinct indices
-        auto seg = [&](int k0, int k1, double acc) { // [k0, k1) cut to this wave's range
-            k0 = k0 > ka ? k0 : ka;
-            k1 = k1 < kb ? k1 : kb;
-            return k0 < k1 ? dot_range(row, xc, k0, k1, acc) : acc;
-        };
-        double s = seg(0, lo, 0.0);
-        s = seg(lo + 1, hi, s);
-        s = seg(hi + 1, d, s);
-        slot[(p * NS + part) * 64] = s;
-        if (part != 0) return; // the uniform is the first dot wave's job
-        double u;
-        if (a.d_U) {
-            u = a.d_U[((int64_t)(j - 1) * d + i) * n + cc];
-        } else {
-            if ((i & 1) == 0) // coordinates are prepared in order, so the odd one finds its uniform waiting
-                philox_uniform2(PhiloxKey(a.seed), (uint64_t)(a.chain_offset + cc), (uint32_t)(a.sweep_offset + j), TAG_GIBBS, (uint32_t)(i >> 1), ua, ub);
-            u = (i & 1) ? ub : ua;
-        }
-        slot[(p * NS + NDOT) * 64] = u;
-    };
-
-    if (dotter) prepare(0, 1, ring, 0);
-    lds_barrier();
-
-    int32_t status = MCMC_CHAIN_OK;
-    double xprev = dotter ? 0.0 : xc[(d - 1) * 64]; // centred x of the previous coordinate
-    int i = 0, j = 1, r0 = 0;  // coordinate, sweep, ring slot of row i
-    for (int64_t t = 0; t < total; ++t) {
-        const int r1 = (r0 == 2) ? 0 : r0 + 1, r2 = (r1 == 2) ? 0 : r1 + 1;
-        const int i1 = (i + 1 == d) ? 0 : i + 1, i2 = (i1 + 1 == d) ? 0 : i1 + 1;
-        const int p = (int)(t & 1);
-        // every thread: fetch row i+2 for the ring
-        double pre[kWideMaxPrefetch];
-#pragma unroll
-        for (int q = 0; q < kWideMaxPrefetch; ++q) {
-            const int e = tid + q * nthreads;
-            pre[q] = (e < W) ? rows[(size_t)i2 * W + e] : 0.0;
-        }
-        if (dotter) {
-            if (t + 1 < total) prepare(i1, i1 == 0 ? j + 1 : j, ring + r1 * W, p ^ 1);
-        } else {
-            const double *const row = ring + r0 * W;
-            const int ja = a.sweep_offset + j; // absolute sweep (resume)
-            const bool keep = a.d_trace && (ja % a.thin) == 0;
-            const bool mom = MOMENTS && j > a.burn;
-            // conditional mean mu_i + P_i (x[-i] - mu[-i])   (tmvrnormGibbs.cpp:124-127)
-            const int prev = (i == 0) ? d - 1 : i - 1;
-            double s = slot[(p * NS) * 64];
-            for (int q = 1; q < NDOT; ++q) s += slot[(p * NS + q) * 64];
-            s += row[prev] * xprev;
-            const double u = slot[(p * NS + NDOT) * 64];
-            const double mui = row[d];
-            const double xi = rtnorm_draw_std<TAIL_SAFE>(u, mui + s, row[d + 1], row[d + 2], row[d + 3], row[d + 4]);
-            xprev = xi - mui;
-            xc[i * 64] = xprev;
-            if (!isfinite(xi) && status == MCMC_CHAIN_OK) status = (ja << 4) | MCMC_CHAIN_NONFINITE_STATE;
-            if (live) {
-                if (keep) a.d_trace[((int64_t)(ja / a.thin - a.sweep_offset / a.thin - 1) * d + i) * n + c] = xi;
-                if (j == a.n_sweeps && a.d_final) a.d_final[(int64_t)i * n + c] = xi;
-                if (mom) { // running sums of the centred draw; no value comes back, so nothing waits for HBM
-                    unsafeAtomicAdd(a.d_mean + (int64_t)i * n + c, xprev);
-                    unsafeAtomicAdd(a.d_m2 + (int64_t)i * n + c, xprev * xprev);
-                }
-            }
-        }
-        // row i+2 goes into the free ring slot (it held row i-1, last read one step ago)
-        double *const nxt = ring + r2 * W;
-#pragma unroll
-        for (int q = 0; q < kWideMaxPrefetch; ++q) {
-            const int e = tid + q * nthreads;
-            if (e < W) nxt[e] = pre[q];
-        }
-        lds_barrier(); // x_i, the slot for step t+1 and row i+2 are in LDS; trace / moment stores stay in flight
-        r0 = r1;
-        i = i1;
-        if (i == 0) ++j;
-    }
-    if (!dotter && live) {
-        if (a.d_status) a.d_status[c] = status;
-        if (MOMENTS) { // sums of (x - mu_k), (x - mu_k)^2 over the kept sweeps -> mean and M2 (sum of squared deviations)
-            __threadfence();
-            const int nm = a.n_sweeps - a.burn;
-            const double inv = nm > 0 ? 1.0 / (double)nm : 0.0;
-            for (int k = 0; k < d; ++k) {
-                const double s1 = a.d_mean[(int64_t)k * n + c], s2 = a.d_m2[(int64_t)k * n + c];
-                a.d_mean[(int64_t)k * n + c] = rows[(size_t)k * W + d] + s1 * inv;
-                a.d_m2[(int64_t)k * n + c] = fma(-s1 * inv, s1, s2);
-            }
-        }
-    }
-}
-
-// Register-state variant, the one that runs for d > 27 (one dot wave per group up to d = 64, two up to 128, four above).  In the kernel above the centred state of 64 chains is d x 512 B of LDS
-// (64 KB at d = 128), so a CU holds two chain groups and the draw wave's dependent chain (~4 400 cycles per
-// coordinate) is hidden only twice over.  Here each of the two dot waves of a group keeps ITS 64 coordinates of the
-// state in registers (static indices only: the dot product is 64 unrolled FMAs against broadcast LDS reads of the
-// row, one LDS read per FMA instead of two; a new x_i arrives through a 512-byte LDS slot and is put in place by a
+// The state lives in REGISTERS (one dot wave per group up to d = 64, two up to 128, four above): with the centred
+// state of 64 chains in LDS (d x 512 B: 64 KB at d = 128) a CU holds two chain groups and the draw wave's dependent
+// chain (~4 400 cycles per coordinate) is hidden only twice over.  Here each dot wave of a group keeps ITS 64
+// coordinates of the state in registers (static indices only: the dot product is 64 unrolled FMAs against broadcast
+// LDS reads of the row, one LDS read per FMA; a new x_i arrives through a 512-byte LDS slot and is put in place by a
 // select sweep over one eight-register block), the LDS holds only the row ring and the hand-over slots, and a
-// workgroup runs four groups = twelve waves.  The ring rows are written with the two entries the dot waves must not
-// use (the coordinate itself and the one being drawn) zeroed; the latter is kept in an extra slot for the draw wave.
+// workgroup runs four groups = twelve waves.
+//
+// Ring row (kRegTail + 64 NDW doubles): entries [0, 64 NDW) are what the dot waves multiply their registers with --
+// P_i with the two entries they must not use (the coordinate itself and the one being drawn) zeroed, and ZERO from d
+// on, so that a 64-wide window never meets anything but P entries and zeros (the bounds may be +-Inf, and Inf * 0 is
+// NaN); the scalars of the coordinate sit behind the window: mu_i, sd_i, 1/sd_i, lower_i, upper_i, the moment shift
+// and P_i[prev(i)] for the draw wave.
 constexpr int kRegOwn = 64;
+constexpr int kRegTail = 8; // mu, sd, 1/sd, lower, upper, shift, P[prev], pad
+constexpr int kRowScalars = 6; // scalars per coordinate in the HBM rows block: mu, sd, 1/sd, lower, upper, shift
 template <int Q>
 struct DotPos {
     static constexpr int value = Q;
@@ -335,7 +149,7 @@ struct DotPos {
 template <bool TAIL_SAFE, bool MOMENTS>
 __global__ __launch_bounds__(768) void gibbs_reg_kernel(const GibbsArgs a, const double *__restrict__ rows, int W, int G, int NDW)
 {
-    extern __shared__ double lds[]; // [3][W + 2] row ring, [G][2][NDW + 1][64] slots (partial sums, u), [G][2][64] new x
+    extern __shared__ double lds[]; // [3][64 NDW + kRegTail] row ring, [G][2][NDW + 1][64] slots (partial sums, u), [G][2][64] new x
     const int NS = NDW + 1;
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int lane = tid & 63;
@@ -344,7 +158,8 @@ __global__ __launch_bounds__(768) void gibbs_reg_kernel(const GibbsArgs a, const
     const int group = dotter ? (wave - G) % G : wave;
     const int part = dotter ? (wave - G) / G : 0;
     const int d = a.d;
-    const int W2 = W + 2;
+    const int TW = NDW * kRegOwn;  // dot-visible entries of a ring row
+    const int W2 = TW + kRegTail;  // ring row stride
     const int64_t c = ((int64_t)blockIdx.x * G + group) * 64 + lane;
     const int64_t n = a.n_chains;
     const bool live = c < n;
@@ -356,15 +171,22 @@ __global__ __launch_bounds__(768) void gibbs_reg_kernel(const GibbsArgs a, const
     const int64_t total = (int64_t)a.n_sweeps * d;
     const int base = part * kRegOwn; // first coordinate this dot wave owns
 
-    // ring row for coordinate i: P_i with the entries i (zero already) and prev(i) zeroed, P_i[prev(i)] at [W]
+    // ring row for coordinate i: P_i with the entries i (zero already) and prev(i) zeroed, P_i[prev(i)] and the
+    // scalars behind the dot waves' window; entries d .. TW-1 keep the zeros written here once
     auto put_row = [&](double *dst, int i, int e, double val) {
         const int prev = (i == 0) ? d - 1 : i - 1;
+        if (e >= d) {
+            if (e < d + kRowScalars) dst[TW + (e - d)] = val;
+            return;
+        }
         if (e == prev) {
-            dst[W] = val;
+            dst[TW + kRowScalars] = val;
             val = 0.0;
         }
         dst[e] = val;
     };
+    for (int e = tid; e < 3 * W2; e += nthreads) ring[e] = 0.0;
+    __syncthreads();
     for (int e = tid; e < 2 * W; e += nthreads) {
         const int r = e / W, k = e - r * W;
         put_row(ring + r * W2, r, k, rows[e]);
@@ -408,7 +230,7 @@ __global__ __launch_bounds__(768) void gibbs_reg_kernel(const GibbsArgs a, const
         }
         double ua = 0.0, ub = 0.0; // the two uniforms of the current Philox block (first dot wave)
         auto prepare = [&](int ip, int jp, const double *row, int p) {
-            const double *const rp = row + base; // entries past d are the row's scalars: finite, and x is zero there
+            const double *const rp = row + base; // base + 63 < TW; entries from d on are zero, and so is x there
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
             for (int k = 0; k < kRegOwn; k += 2) {
@@ -496,19 +318,21 @@ __global__ __launch_bounds__(768) void gibbs_reg_kernel(const GibbsArgs a, const
             // conditional mean mu_i + P_i (x[-i] - mu[-i])   (tmvrnormGibbs.cpp:124-127)
             double s = slot[(p * NS) * 64];
             for (int q = 1; q < NDW; ++q) s += slot[(p * NS + q) * 64];
-            s += row[W] * xprev;
+            const double *const sc = row + TW; // mu, sd, 1/sd, lower, upper, shift, P_i[prev]
+            s += sc[kRowScalars] * xprev;
             const double u = slot[(p * NS + NDW) * 64];
-            const double mui = row[d];
-            const double xi = rtnorm_draw_std<TAIL_SAFE>(u, mui + s, row[d + 1], row[d + 2], row[d + 3], row[d + 4]);
+            const double mui = sc[0];
+            const double xi = rtnorm_draw_std<TAIL_SAFE>(u, mui + s, sc[1], sc[2], sc[3], sc[4]);
             xprev = xi - mui;
             xnew[p * 64] = xprev;
             if (!isfinite(xi) && status == MCMC_CHAIN_OK) status = (ja << 4) | MCMC_CHAIN_NONFINITE_STATE;
             if (live) {
                 if (keep) a.d_trace[((int64_t)(ja / a.thin - a.sweep_offset / a.thin - 1) * d + i) * n + c] = xi;
                 if (j == a.n_sweeps && a.d_final) a.d_final[(int64_t)i * n + c] = xi;
-                if (mom) {
-                    unsafeAtomicAdd(a.d_mean + (int64_t)i * n + c, xprev);
-                    unsafeAtomicAdd(a.d_m2 + (int64_t)i * n + c, xprev * xprev);
+                if (mom) { // running sums of x - shift_i and its square; no value comes back, so nothing waits for HBM
+                    const double xs = xi - sc[5];
+                    unsafeAtomicAdd(a.d_mean + (int64_t)i * n + c, xs);
+                    unsafeAtomicAdd(a.d_m2 + (int64_t)i * n + c, xs * xs);
                 }
             }
         }
@@ -520,13 +344,15 @@ __global__ __launch_bounds__(768) void gibbs_reg_kernel(const GibbsArgs a, const
     }
     if (live) {
         if (a.d_status) a.d_status[c] = status;
-        if (MOMENTS) {
+        if (MOMENTS) { // sums of (x - shift_k), (x - shift_k)^2 over the counted sweeps -> mean and M2 (sum of squared deviations).
+            // shift_k is the point of [lower_k, upper_k] nearest mu_k (launch_gibbs): within the spread of the draws
+            // of the data in the tail cases too, so the difference below cancels few digits
             __threadfence();
             const int nm = a.n_sweeps - a.burn;
             const double inv = nm > 0 ? 1.0 / (double)nm : 0.0;
             for (int k = 0; k < d; ++k) {
                 const double s1 = a.d_mean[(int64_t)k * n + c], s2 = a.d_m2[(int64_t)k * n + c];
-                a.d_mean[(int64_t)k * n + c] = rows[(size_t)k * W + d] + s1 * inv;
+                a.d_mean[(int64_t)k * n + c] = rows[(size_t)k * W + d + 5] + s1 * inv;
                 a.d_m2[(int64_t)k * n + c] = fma(-s1 * inv, s1, s2);
             }
         }
@@ -596,7 +422,7 @@ int launch_gibbs(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipSt
     }
     const bool moments = a.d_mean != nullptr;
     if (d > kGibbsLaneMaxDim) { // wide variant: rows of W doubles, shared by the waves of a workgroup
-        const int W = (d + 5 + 1) & ~1;
+        const int W = (d + kRowScalars + 1) & ~1;
         std::vector<double> rows((size_t)d * W + d, 0.0);
         for (int i = 0; i < d; ++i) {
             double *r = rows.data() + (size_t)i * W;
@@ -607,72 +433,38 @@ int launch_gibbs(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipSt
             r[d + 2] = 1.0 / p.sd[i];
             r[d + 3] = p.lower[i];
             r[d + 4] = p.upper[i];
+            r[d + 5] = std::fmin(std::fmax(p.mu[i], p.lower[i]), p.upper[i]); // moment shift: the point of the box nearest mu (finite)
         }
         for (int k = 0; k < d; ++k) rows[(size_t)d * W + k] = p.init[k];
-        if (!std::getenv("MCMC_GIBBS_NO_REG")) { // state in the dot waves' registers, 64 coordinates each (the LDS-state
-                                                  // kernel below stays for comparison: MCMC_GIBBS_NO_REG=1)
-            const int NDW = d <= kRegOwn ? 1 : (d <= 2 * kRegOwn ? 2 : 4); // dot waves per group; functions of d only
-            const int G = NDW == 1 ? 6 : (NDW == 2 ? 4 : 2);               // groups per workgroup: 12 / 12 / 10 waves, three per SIMD at most
-            const size_t ldsr = ((size_t)3 * (W + 2) + (size_t)G * (2 * (NDW + 1) * 64 + 128)) * sizeof(double);
-            double *d_rows = nullptr;
-            MCMC_HIP_CHECK(hipMallocAsync((void **)&d_rows, rows.size() * sizeof(double), s));
-            MCMC_HIP_CHECK(hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, s));
-            MCMC_HIP_CHECK(hipStreamSynchronize(s)); // rows is a local: do not let the copy outlive it
-            const int64_t gridr = (a.n_chains + 64 * G - 1) / (64 * G);
-            auto gor = [&](auto kern) -> int {
-                hipLaunchKernelGGL(kern, dim3((unsigned)gridr), dim3(G * (1 + NDW) * 64), ldsr, s, a, (const double *)d_rows, W, G, NDW);
-                MCMC_HIP_CHECK(hipGetLastError());
-                return MCMC_OK;
-            };
-            int rcr;
-            if (tail_safe)
-                rcr = moments ? gor(gibbs_reg_kernel<true, true>) : gor(gibbs_reg_kernel<true, false>);
-            else
-                rcr = moments ? gor(gibbs_reg_kernel<false, true>) : gor(gibbs_reg_kernel<false, false>);
-            hipError_t er = hipFreeAsync(d_rows, s);
-            if (rcr == MCMC_OK && er != hipSuccess) rcr = set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(er));
-            return rcr;
-        }
-        const size_t state = (size_t)d * 64 * sizeof(double), rowb = (size_t)3 * W * sizeof(double);
-        // chain groups per workgroup: what 160 KB of LDS hold (per group the state and at most 3 KB of hand-over slots)
-        int nw = (int)((160 * 1024 - rowb - 256) / (state + 3072));
-        // more than four groups (measured, LDS permitting: d = 34 six groups +14 %, d = 48 five groups -17 %) is no
-        // consistent gain: the per-step barrier spans all waves of the workgroup
-        int nw_cap = 4;
-        if (const char *env = std::getenv("MCMC_GIBBS_GROUPS")) nw_cap = std::atoi(env) > 0 ? std::atoi(env) : 4; // tuning hook
-        nw = nw < 1 ? 1 : (nw > nw_cap ? nw_cap : nw);
-        // dot waves per group: nw (1 + ndot) waves per workgroup, at most 16; a function of d only, so that results
-        // do not depend on how chains are split over launches
-        // (measured at d = 128, two groups: 1 / 2 / 3 / 5 / 7 dot waves -> 507 / 393 / 403 / 522 / 470 ms; beyond two the
-        // per-step barrier over more waves costs more than the shorter sums save, and the draw wave is the bound)
-        int ndot = 16 / nw - 1;
-        ndot = ndot > 2 ? 2 : ndot;
-        if (const char *env = std::getenv("MCMC_GIBBS_NDOT")) { // tuning hook
-            const int v = std::atoi(env);
-            if (v >= 1 && v <= 7 && nw * (1 + v) <= 16) ndot = v;
-        }
-        const int threads = nw * (1 + ndot) * 64;
+        // state in the dot waves' registers, 64 coordinates each; group and wave counts are functions of d only, so
+        // that results do not depend on how chains are split over launches
+        const int NDW = d <= kRegOwn ? 1 : (d <= 2 * kRegOwn ? 2 : 4); // dot waves per group
+        const int G = NDW == 1 ? 6 : (NDW == 2 ? 4 : 2);               // groups per workgroup: 12 / 12 / 10 waves, three per SIMD at most
+        const int threads = G * (1 + NDW) * 64;
         if ((W + threads - 1) / threads > kWideMaxPrefetch) return set_error(MCMC_E_UNSUPPORTED, "gibbs: d=%d too wide", d);
-        const size_t ldsw = rowb + (size_t)nw * (2 * (ndot + 1) * 64) * sizeof(double) + nw * state;
+        const size_t ldsr = ((size_t)3 * (NDW * kRegOwn + kRegTail) + (size_t)G * (2 * (NDW + 1) * 64 + 128)) * sizeof(double);
         double *d_rows = nullptr;
         MCMC_HIP_CHECK(hipMallocAsync((void **)&d_rows, rows.size() * sizeof(double), s));
-        MCMC_HIP_CHECK(hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, s));
-        MCMC_HIP_CHECK(hipStreamSynchronize(s)); // rows is a local: do not let the copy outlive it
-        const int64_t gridw = (a.n_chains + 64 * nw - 1) / (64 * nw);
-        auto gow = [&](auto kern) -> int {
-            MCMC_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
-            hipLaunchKernelGGL(kern, dim3((unsigned)gridw), dim3(threads), ldsw, s, a, (const double *)d_rows, W, nw, ndot);
-            MCMC_HIP_CHECK(hipGetLastError());
-            return MCMC_OK;
+        hipError_t ec = hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, s);
+        if (ec == hipSuccess) ec = hipStreamSynchronize(s); // rows is a local: do not let the copy outlive it
+        if (ec != hipSuccess) {
+            (void)hipFreeAsync(d_rows, s);
+            return set_error(MCMC_E_HIP, "gibbs: parameter upload failed: %s", hipGetErrorString(ec));
+        }
+        const int64_t gridr = (a.n_chains + 64 * G - 1) / (64 * G);
+        auto gor = [&](auto kern) -> int {
+            hipLaunchKernelGGL(kern, dim3((unsigned)gridr), dim3(threads), ldsr, s, a, (const double *)d_rows, W, G, NDW);
+            hipError_t el = hipGetLastError();
+            return el == hipSuccess ? MCMC_OK : set_error(MCMC_E_HIP, "gibbs_reg_kernel launch failed: %s", hipGetErrorString(el));
         };
-        int rcw;
+        int rcr;
         if (tail_safe)
-            rcw = moments ? gow(gibbs_wide_kernel<true, true>) : gow(gibbs_wide_kernel<true, false>);
+            rcr = moments ? gor(gibbs_reg_kernel<true, true>) : gor(gibbs_reg_kernel<true, false>);
         else
-            rcw = moments ? gow(gibbs_wide_kernel<false, true>) : gow(gibbs_wide_kernel<false, false>);
-        hipError_t ew = hipFreeAsync(d_rows, s);
-        if (rcw == MCMC_OK && ew != hipSuccess) rcw = set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(ew));
-        return rcw;
+            rcr = moments ? gor(gibbs_reg_kernel<false, true>) : gor(gibbs_reg_kernel<false, false>);
+        hipError_t er = hipFreeAsync(d_rows, s);
+        if (rcr == MCMC_OK && er != hipSuccess) rcr = set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(er));
+        return rcr;
     }
     double *d_prm = nullptr;
     MCMC_HIP_CHECK(hipMallocAsync((void **)&d_prm, blob.size() * sizeof(double), s));

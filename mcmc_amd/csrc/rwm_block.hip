@@ -399,8 +399,21 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
                 b *= b;
             }
             const double dt = sp * prodR;
+            double det = dt * dt;
+            if (!(det > 1e-280 && det < 1e280)) {
+                // Near under / overflow the way the product is formed decides WHEN it reaches 0 or Inf, and from that
+                // iteration on the reference rejects every proposal (rootTerm = Inf or 0 -> p = +-Inf -> la = NaN, :56,
+                // :169-175; at d = 100 with covmat = I this happens once scaling_sd < 0.0241).  arma::det is the running
+                // product of the LU diagonal, here diag(U)_k = s^2 R_kk^2: the same product in the same order.
+                const double s2 = mul_rn(s_eff, s_eff);
+                det = 1.0;
+                for (int k = 0; k < d; ++k) {
+                    const double rkk = A[tri(k, k)];
+                    det = mul_rn(det, mul_rn(s2, mul_rn(rkk, rkk)));
+                }
+            }
             double sq_unused;
-            fm_sqrt_rsq(a.twopi_pow_d * (dt * dt), sq_unused, rootTerm);
+            fm_sqrt_rsq(a.twopi_pow_d * det, sq_unused, rootTerm); // det = 0 or Inf gives NaN here, Inf / 0 in the reference: la is NaN either way
         }
 
         // ---- draws: d normals, then one uniform (:149-152,174) ----------------------------------------

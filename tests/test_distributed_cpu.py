@@ -107,3 +107,33 @@ def test_pooled_covariance_from_partial_sums_of_two_shards():
     flat = draws.transpose(1, 0, 2).reshape(d, -1)
     np.testing.assert_allclose(mbar, flat.mean(1), rtol=1e-12)
     np.testing.assert_allclose(S, np.cov(flat, bias=True), rtol=1e-11, atol=1e-13)
+
+
+def _run_bench(args, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, [json.loads(ln) for ln in lines], p.stderr
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` run plainly (no launcher) must start two ranks itself, not silently run one
+    (the job of mclapply_RNG, MCMCutilty.R:103-149).  --rehearse skips the kernels so this runs without a GPU: the
+    rank start-up, the barriers, the max-over-ranks clock and the all-reduce are the real ones (gloo)."""
+    rc, lines, err = _run_bench(["--gpus", "2", "--rehearse", "--steps", "2", "--chains", "100"])
+    assert rc == 0, err
+    assert len(lines) == 1  # rank 0 alone prints
+    assert lines[0]["n_gpus"] == 2 and lines[0]["collective_ranks"] == 2 and lines[0]["chain_offsets"] == [0, 100]
+    # a launcher that set WORLD_SIZE to something else than --gpus is an error, not a one-GPU run labelled N
+    rc, lines, err = _run_bench(["--gpus", "2", "--rehearse"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert rc != 0 and not lines and "WORLD_SIZE=1" in err
+    # under a launcher (WORLD_SIZE == --gpus) the process is one rank and starts nothing
+    rc, lines, err = _run_bench(["--gpus", "1", "--rehearse", "--steps", "1"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert rc == 0 and lines[0]["n_gpus"] == 1, err

@@ -50,3 +50,24 @@ def test_gibbs_smallest_shapes(cuda, oracle, d, nc, n):
         want = oracle.rtmvnorm_gibbs(n, mu, sigma, lower, upper, init, U[:, :, c].reshape(-1))
         assert _rel(out["trace"].cpu().numpy()[:, :, c], want) < RTOL
     assert cuda.equal(out["final_state"], out["trace"][-1])
+
+
+def test_bench_two_ranks_on_one_gpu(cuda):
+    """bench.py --gpus 2 run plainly: two child ranks (gloo here, since both share the one GPU of the test box; RCCL
+    on a real node), chains keyed by global id, ONE JSON line with n_gpus = 2 and the all-reduced diagnostics."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MCMC_BENCH_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--chains", "512", "--iters", "400",
+                        "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    ln = lines[0]
+    assert ln["n_gpus"] == 2 and ln["collective_ranks"] == 2 and ln["config"]["chains_per_gpu"] == 512
+    assert ln["value"] > 0 and ln["chains_failed"] == 0 and ln["rhat_max"] is not None and ln["ess_per_sec"] > 0

@@ -128,3 +128,85 @@ def test_c5_share_full_size_tail_law_and_sharding(cuda):
     part = mcmc_amd.tmvn_gibbs_batch(cnt, n, *args, lower + 0.1, chain_offset=lo, **kw)
     assert cuda.equal(part["final_state"], x[:, lo:lo + cnt])
     np.testing.assert_allclose(part["mean"].cpu().numpy(), out["mean"][:, lo:lo + cnt].cpu().numpy(), rtol=1e-12)
+
+
+def test_c4_share_full_size_collapse_sharding_and_resume(cuda):
+    """C4 as specified, per-GPU share: d = 100, covmat I, adapt 200/1000, 131 072 chains x 5 000 iterations, trace
+    thinned x10.  On these inputs EVERY chain of the reference ends in permanent NaN-reject around iteration 220
+    (det(scaling_sd^2 I) underflows in mvrnorm_pdf, adaptMCMC_source.cpp:56,169-175; the small-size oracle test is
+    tests/test_gpu_rwm.py::test_c4_exact_inputs_size_phase_collapse_matches_oracle), so the size-independent
+    properties are: status 0, no chain ever reaches the shape phase, every chain is constant from row 30
+    (iteration 300) on, and every chain is bit-identical under re-sharding and under splitting the run."""
+    import mcmc_amd
+
+    d, nc, n, thin = 100, 131072, 5000, 10
+    A = np.random.default_rng(4).standard_normal((d, d))
+    H = np.linalg.inv(A @ A.T / d + np.eye(d))
+    H = 0.5 * (H + H.T)
+    tgt = mcmc_amd.Target.gaussian(np.zeros(d), H)
+    init = mcmc_amd.init_normal(1, nc, np.zeros(d), 1.0)
+    kw = dict(seed=1, thin=thin)
+    ad = (200, 0.0, 0, 1000)
+    out = mcmc_amd.adapt_rwm_batch(tgt, nc, init, np.eye(d), n, *ad, **kw)
+    assert int((out["status"] != 0).sum()) == 0
+    tr = out["theta_trace"]
+    assert tuple(tr.shape) == (n // thin, d, nc)
+    assert int(out["shape_iterations"].sum()) == 0
+    assert bool((tr[30:] == tr[30:31]).all())                # frozen for good ...
+    assert bool((tr[25] != tr[0]).any(dim=0).float().mean() > 0.9)  # ... after a few accepted moves just before
+    acc = out["acceptance_rate"]
+    assert float(acc.max()) < 30.0 / n
+    lo, cnt = 100001, 1000
+    part = mcmc_amd.adapt_rwm_batch(tgt, cnt, init[:, lo:lo + cnt].contiguous(), np.eye(d), n, *ad, chain_offset=lo, **kw)
+    assert cuda.equal(part["theta_trace"], tr[:, :, lo:lo + cnt])
+    assert cuda.equal(part["acceptance_rate"], acc[lo:lo + cnt])
+    a = mcmc_amd.adapt_rwm_batch(tgt, nc, init, np.eye(d), 213, *ad, checkpoint=True, trace=False, **kw)  # cut inside the collapse
+    b = mcmc_amd.adapt_rwm_batch(tgt, nc, init, np.eye(d), n - 213, *ad, resume=a["state"], **kw)
+    assert cuda.equal(b["theta_trace"], tr[21:])
+    for k in ("final_theta", "final_mean", "final_cov", "acceptance_rate", "shape_iterations"):
+        assert cuda.equal(b[k], out[k]), k
+
+
+def test_c4s_shape_phase_at_scale_law_sharding_and_resume(cuda):
+    """The non-degenerate d = 100 workload (bench.py --workload c4s: covmat 0.05 I, size adaptation off,
+    adapt_shape_start 1000) on 4 096 chains x 5 000 iterations -- a thirty-second of the per-GPU share, because a
+    full-size launch spends ~30 s in the d^3/3 factorizations: the shape phase is reached by every chain, the pooled
+    draws stay symmetric about 0, and chains are bit-identical under re-sharding and splitting the run."""
+    import mcmc_amd
+
+    d, nc, n, thin = 100, 4096, 5000, 10
+    A = np.random.default_rng(4).standard_normal((d, d))
+    Sig = A @ A.T / d + np.eye(d)
+    H = np.linalg.inv(Sig)
+    H = 0.5 * (H + H.T)
+    tgt = mcmc_amd.Target.gaussian(np.zeros(d), H)
+    init = mcmc_amd.init_normal(1, nc, np.zeros(d), 1.0)
+    cov0 = 0.05 * np.eye(d)
+    kw = dict(seed=1, thin=thin)
+    ad = (0, 0.0, 0, 1000)
+    out = mcmc_amd.adapt_rwm_batch(tgt, nc, init, cov0, n, *ad, **kw)
+    assert int((out["status"] != 0).sum()) == 0
+    si = out["shape_iterations"].double()
+    assert float(si.min()) > 500 and 0.25 < float(si.mean()) / n < 0.65
+    acc = out["acceptance_rate"]
+    assert 0.2 < float(acc.mean()) < 0.6
+    tr = out["theta_trace"]
+    x = tr[400:]                                             # the last 1 000 iterations, all chains in the shape phase
+    mean = x.mean(dim=(0, 2)).cpu().numpy()
+    var = x.var(dim=(0, 2)).cpu().numpy()
+    assert np.max(np.abs(mean)) < 0.1, np.max(np.abs(mean))
+    # NOT a draw from N(0, Sigma) yet, and not for lack of kernel correctness: covmat_empirical after ~2 800 plain
+    # random-walk iterations holds ~11 autocorrelation times' worth of information about a 100 x 100 matrix (its
+    # eigenvalues span 0.02 .. 18 where Sigma's span 1 .. 4.5), the reference adds no regularising eps I to it
+    # (adaptMCMC_source.cpp:138), and x^T H x sinks from ~100 (= d, equilibrium of the plain walk) to ~40 once the
+    # shape phase starts -- the oracle and an independent numpy restatement do exactly the same.  What holds at
+    # every iteration is the symmetry under x -> -x checked above; the pooled variance is only bracketed.
+    assert np.all(var > 0.3) and np.all(var < 1.15 * np.diag(Sig)), (var.min(), (var / np.diag(Sig)).max())
+    lo, cnt = 3000, 500
+    part = mcmc_amd.adapt_rwm_batch(tgt, cnt, init[:, lo:lo + cnt].contiguous(), cov0, n, *ad, chain_offset=lo, **kw)
+    assert cuda.equal(part["theta_trace"], tr[:, :, lo:lo + cnt])
+    a = mcmc_amd.adapt_rwm_batch(tgt, nc, init, cov0, 3333, *ad, checkpoint=True, trace=False, **kw)
+    b = mcmc_amd.adapt_rwm_batch(tgt, nc, init, cov0, n - 3333, *ad, resume=a["state"], **kw)
+    assert cuda.equal(b["theta_trace"], tr[333:])
+    for k in ("final_theta", "final_mean", "final_cov", "acceptance_rate", "shape_iterations"):
+        assert cuda.equal(b[k], out[k]), k

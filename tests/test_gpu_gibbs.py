@@ -25,6 +25,18 @@ def _tol(want, mu, sd):
     return RTOL * np.maximum(1.0, np.abs(want)) + sd * 4 * EPS / np.maximum(_norm.pdf(z), 1e-300)
 
 
+def _cond_tol(want, init, mu, P, sd):
+    """`_tol` with the conditional mean each draw was made around (tmvrnormGibbs.cpp:124-127), rebuilt from the
+    oracle's own trajectory: coordinate i of sweep j sees x_0..x_(i-1) of sweep j and x_(i+1).. of sweep j-1."""
+    n, d = want.shape
+    prev = np.vstack([np.asarray(init, dtype=np.float64)[None, :], want[:-1]])
+    tol = np.empty_like(want)
+    for i in range(d):
+        x = np.concatenate([want[:, :i], prev[:, i + 1:]], axis=1) - np.delete(mu, i)[None, :]
+        tol[:, i] = _tol(want[:, i], mu[i] + x @ P[i], sd[i])
+    return tol
+
+
 def _c3_params(d=10, rho=0.5, lo=-1.0, hi=2.0):
     idx = np.arange(d)
     sigma = rho ** np.abs(idx[:, None] - idx[None, :])
@@ -70,11 +82,9 @@ def test_reference_fixtures_single_chain(cuda, oracle, name):
     got = mcmc_amd.rtmvnorm_gibbs(n, g["mu"], g["sigma"], g["lower"], g["upper"], g["init"], U=g["U"])
     assert got.shape == (n, g["mu"].size)
     want = g["trace"]
-    _, _, sd = oracle.tmvn_precompute(g["sigma"])
-    # conditional means are not stored; bound the conditioning term with the marginal centre
-    tol = np.stack([_tol(want[:, k], g["mu"][k], sd[k]) for k in range(want.shape[1])], axis=1)
-    assert np.all(np.abs(got - want) <= 50 * tol), np.max(np.abs(got - want) / tol)
-    assert np.max(np.abs(got - want) / np.maximum(1, np.abs(want))) < 1e-11
+    _, P, sd = oracle.tmvn_precompute(g["sigma"])
+    tol = _cond_tol(want, g["init"], g["mu"], P, sd)  # 1e-12 relative + the formula's own conditioning, per draw
+    assert np.all(np.abs(got - want) <= tol), np.max(np.abs(got - want) / tol)
 
 
 def test_precompute_matches_reference_partitioning(oracle):
@@ -135,6 +145,40 @@ def test_batch_lds_kernel_injected(cuda, oracle, d, n_chains, n_sweeps):
         assert err < RTOL, (c, err)
         np.testing.assert_array_equal(out["final_state"].cpu().numpy()[:, c], trace[-1, :, c])
         np.testing.assert_allclose(out["mean"].cpu().numpy()[:, c], want[2:].mean(axis=0), rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(out["m2"].cpu().numpy()[:, c], ((want[2:] - want[2:].mean(0)) ** 2).sum(0), rtol=1e-10)
+
+
+@pytest.mark.parametrize("tail_safe", [False, True])
+@pytest.mark.parametrize("d,n_chains,n_sweeps", [(28, 70, 12), (48, 130, 12), (100, 70, 8), (129, 65, 5), (200, 65, 4)])
+def test_wide_kernel_infinite_bounds(cuda, oracle, d, n_chains, n_sweeps, tail_safe):
+    """One-sided truncation (the reference's own example is c(-Inf,-Inf,0,0), tmvrnormGibbs.cpp:146) in the d > 27
+    kernel: a dot wave's 64-wide window must never meet the +-Inf bounds (Inf * 0 = NaN).  d is chosen so that the
+    window of the last dot wave runs past coordinate d (28, 48 < 64; 100 < 128; 129, 200 < 256)."""
+    import mcmc_amd
+
+    rng = np.random.default_rng(300 + d)
+    mu, sigma, _, _, _ = _c3_params(d, rho=0.3)
+    mu = mu + 0.02 * np.arange(d)
+    k = np.arange(d)
+    lower = np.where(k % 3 == 0, -np.inf, -1.0)
+    upper = np.where(k % 3 == 1, np.inf, 2.0)
+    lower[-1], upper[-1] = -np.inf, np.inf  # and an untruncated coordinate, both bounds infinite
+    init = rng.uniform(-0.5, 1.5, size=(d, n_chains))
+    U = rng.random((n_sweeps, d, n_chains))
+    out = mcmc_amd.tmvn_gibbs_batch(n_chains, n_sweeps, mu, sigma, lower, upper, cuda.tensor(init, device="cuda"),
+                                    U=cuda.tensor(U, device="cuda"), moments=True, tail_safe=tail_safe)
+    cuda.cuda.synchronize()
+    assert np.all(out["status"].cpu().numpy() == 0)
+    trace = out["trace"].cpu().numpy()
+    assert np.all(np.isfinite(trace))
+    _, P, sd = oracle.tmvn_precompute(sigma)
+    for c in (0, 63, n_chains - 1):
+        want = oracle.rtmvnorm_gibbs(n_sweeps, mu, sigma, lower, upper, init[:, c], U[:, :, c].reshape(-1))
+        tol = _cond_tol(want, init[:, c], mu, P, sd)
+        assert np.all(np.abs(trace[:, :, c] - want) <= tol), (c, np.max(np.abs(trace[:, :, c] - want) / tol))
+        np.testing.assert_allclose(out["mean"].cpu().numpy()[:, c], trace[:, :, c].mean(axis=0), rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(out["m2"].cpu().numpy()[:, c], ((trace[:, :, c] - trace[:, :, c].mean(0)) ** 2).sum(0),
+                                   rtol=1e-10)
 
 
 def test_thinning_keeps_every_kth_sweep(cuda):
@@ -282,3 +326,5 @@ def test_wide_kernel_philox_replay_sharding_thinning_and_tail(cuda, oracle):
     assert cuda.equal(o2["final_state"], o["final_state"]) and cuda.equal(o2["mean"], o["mean"])
     tr = o2["trace"][10:].cpu().numpy()
     np.testing.assert_allclose(m, tr.mean(axis=0), rtol=1e-12)
+    # M2 in the tail case: the draws sit ~4.2 sd from mu with a spread of ~0.2 sd; the sums run around the bound
+    np.testing.assert_allclose(o["m2"].cpu().numpy(), ((tr - tr.mean(axis=0)) ** 2).sum(axis=0), rtol=1e-10)
