@@ -407,7 +407,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
                 // product of the LU diagonal, here diag(U)_k = s^2 R_kk^2: the same product in the same order.
                 const double s2 = mul_rn(s_eff, s_eff);
                 det = 1.0;
-                for (int k = 0; k < d; ++k) {
+                for (int k = 0; k < d && det != 0.0; ++k) { // once 0 it stays 0 (every factor is finite)
                     const double rkk = A[tri(k, k)];
                     det = mul_rn(det, mul_rn(s2, mul_rn(rkk, rkk)));
                 }
