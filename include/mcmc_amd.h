@@ -294,6 +294,21 @@ typedef struct mcmc_gibbs_io {
 
 int mcmc_tmvn_gibbs_batch(const mcmc_gibbs_config *cfg, const mcmc_gibbs_io *io, void *stream);
 
+/*
+ * The same call for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  mcmc_tmvn_gibbs_batch stages its shared
+ * parameter block (regression rows P_i, sd_i, bounds: tmvrnormGibbs.cpp:100-113) in a hipMallocAsync'ed buffer and
+ * waits for the upload; this variant keeps the block in a static 160 KB device array of the library (one copy per
+ * GPU, held until the process ends), fills it through kernel arguments and calls no hipMalloc / hipFree /
+ * hipMemcpy / stream synchronisation: every step is a kernel launch on `stream`.  Same kernels, bit-identical results.
+ * Limits: d <= mcmc_tmvn_gibbs_noalloc_max_dim() (= 139: the block of a larger d does not fit the array; MCMC_E_UNSUPPORTED).
+ * Every call on a GPU uses that GPU's one array (and one host staging area): calls that overlap on one GPU -- from
+ * two host threads, or on two streams while the first call's kernel is still running -- race; calls on different
+ * GPUs do not.
+ */
+int mcmc_tmvn_gibbs_batch_noalloc(const mcmc_gibbs_config *cfg, const mcmc_gibbs_io *io, void *stream);
+int mcmc_tmvn_gibbs_noalloc_max_dim(void);
+
 /* The shared precompute of tmvrnormGibbs.cpp:100-113 (regression rows P_i and conditional
  * sd_i), obtained from the precision matrix H = sigma^-1: P_i = -H[i,-i]/H_ii,
  * sd_i = 1/sqrt(H_ii).  h_P is d rows of d-1 entries (row-major), h_sd is [d]. */

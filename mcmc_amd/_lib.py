@@ -104,6 +104,8 @@ SIGNATURES = {
     "mcmc_rwMCMC": (C.c_int, [C.POINTER(McmcTarget), C.c_int32, dp, dp, C.c_int32, C.c_int32, C.c_double, dp, dp,
                               dp, dp, ip]),
     "mcmc_tmvn_gibbs_batch": (C.c_int, [C.POINTER(GibbsConfig), C.POINTER(GibbsIO), vp]),
+    "mcmc_tmvn_gibbs_batch_noalloc": (C.c_int, [C.POINTER(GibbsConfig), C.POINTER(GibbsIO), vp]),
+    "mcmc_tmvn_gibbs_noalloc_max_dim": (C.c_int, []),
     "mcmc_tmvn_precompute": (C.c_int, [C.c_int32, dp, dp, dp]),
     "mcmc_gibbs_streams": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, vp]),
     "mcmc_rtmvnorm_gibbs": (C.c_int, [C.c_int32, C.c_int32, dp, dp, dp, dp, dp, dp, C.c_uint64, dp]),

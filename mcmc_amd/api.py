@@ -440,7 +440,7 @@ def init_normal(seed, n_chains, mean, sd, chain_offset=0, device="cuda"):
 
 def tmvn_gibbs_batch(n_chains, n_sweeps, mu, sigma, lower, upper, init_state, *, seed=0, thin=1, burn=0,
                      chain_offset=0, U=None, tail_safe=False, trace=True, final=True, moments=False,
-                     out=None, device="cuda", sweep_offset=0):
+                     out=None, device="cuda", sweep_offset=0, no_alloc=False):
     """Many independent rtmvnorm_gibbs chains in one launch (tmvrnormGibbs.cpp:91-142 per chain).
 
     init_state: length-d vector shared by all chains, or a [d, n_chains] CUDA tensor.
@@ -449,6 +449,8 @@ def tmvn_gibbs_batch(n_chains, n_sweeps, mu, sigma, lower, upper, init_state, *,
     moments=True mean / m2 [d, n_chains] over sweeps > burn.
     Resume: pass the previous call's final_state as init_state and sweep_offset = sweeps done; the
     continuation is bit-identical to one uninterrupted call (the chain state of this sampler is x alone).
+    no_alloc=True goes through mcmc_tmvn_gibbs_batch_noalloc: the library allocates nothing (pass every output in
+    `out`), d <= 139, calls on one GPU must not overlap.
     """
     torch = _torch()
     f64 = torch.float64
@@ -491,7 +493,8 @@ def tmvn_gibbs_batch(n_chains, n_sweeps, mu, sigma, lower, upper, init_state, *,
     io.d_mean = _dev_ptr(buf("mean", (d, n_chains), want=moments))
     io.d_m2 = _dev_ptr(buf("m2", (d, n_chains), want=moments))
     io.d_status = _dev_ptr(buf("status", (n_chains,), torch.int32))
-    check(lib.mcmc_tmvn_gibbs_batch(C.byref(cfg), C.byref(io), _stream_ptr()))
+    entry = lib.mcmc_tmvn_gibbs_batch_noalloc if no_alloc else lib.mcmc_tmvn_gibbs_batch
+    check(entry(C.byref(cfg), C.byref(io), _stream_ptr()))
     return out
 
 

@@ -370,7 +370,7 @@ extern "C" int mcmc_tmvn_precompute(int32_t d, const double *h_sigma, double *h_
     return MCMC_OK;
 }
 
-extern "C" int mcmc_tmvn_gibbs_batch(const mcmc_gibbs_config *cfg, const mcmc_gibbs_io *io, void *stream)
+static int tmvn_gibbs_batch_impl(const mcmc_gibbs_config *cfg, const mcmc_gibbs_io *io, void *stream, bool noalloc)
 {
     if (!cfg || !io) return set_error(MCMC_E_BAD_ARG, "mcmc_tmvn_gibbs_batch: NULL argument");
     const int d = cfg->d;
@@ -409,8 +409,21 @@ extern "C" int mcmc_tmvn_gibbs_batch(const mcmc_gibbs_config *cfg, const mcmc_gi
     a.d_mean = io->d_mean;
     a.d_m2 = io->d_m2;
     a.d_status = io->d_status;
+    if (noalloc) return launch_gibbs_noalloc(a, p, cfg->tail_safe != 0, (hipStream_t)stream);
     return launch_gibbs(a, p, cfg->tail_safe != 0, (hipStream_t)stream);
 }
+
+extern "C" int mcmc_tmvn_gibbs_batch(const mcmc_gibbs_config *cfg, const mcmc_gibbs_io *io, void *stream)
+{
+    return tmvn_gibbs_batch_impl(cfg, io, stream, false);
+}
+
+extern "C" int mcmc_tmvn_gibbs_batch_noalloc(const mcmc_gibbs_config *cfg, const mcmc_gibbs_io *io, void *stream)
+{
+    return tmvn_gibbs_batch_impl(cfg, io, stream, true);
+}
+
+extern "C" int mcmc_tmvn_gibbs_noalloc_max_dim(void) { return gibbs_noalloc_max_dim(); }
 
 extern "C" int mcmc_gibbs_streams(uint64_t seed, int64_t chain_offset, int64_t n_chains, int32_t n_sweeps, int32_t d,
                                   double *d_U, void *stream)

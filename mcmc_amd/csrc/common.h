@@ -67,6 +67,8 @@ struct GibbsParams {
 };
 
 int launch_gibbs(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipStream_t s);
+int launch_gibbs_noalloc(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipStream_t s); // static device scratch
+int gibbs_noalloc_max_dim();
 int launch_gibbs_streams(uint64_t seed, int64_t chain_offset, int64_t n_chains, int32_t n_sweeps,
                          int32_t d, double *d_U, hipStream_t s);
 int launch_rtnorm(int64_t n, double mu, double sigma, double a, double b, const double *d_F,

@@ -17,6 +17,8 @@
 //     the loop and then spilling them to VGPR lanes (v_readlane in the hot loop).
 //   * samples: one coalesced store per coordinate and kept sweep, trace[(t*d+k)*n + c] --
 //     512 contiguous bytes per wavefront.
+#include <mutex>
+
 #include "common.h"
 #include "normal_cdf.h"
 #include "philox.h"
@@ -404,28 +406,22 @@ __global__ __launch_bounds__(256) void rtnorm_kernel(int64_t n, double mu, doubl
 }
 
 // ------------------------------------------------------------------------------------------
-int launch_gibbs(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipStream_t s)
+// Shared parameter block of a Gibbs launch: the lane kernel's blob (d <= kGibbsLaneMaxDim) or the wide kernel's rows.
+static size_t gibbs_block_doubles(int d)
 {
-    const int d = a.d;
-    if (d < 1 || d > kMaxDimGibbs) return set_error(MCMC_E_UNSUPPORTED, "gibbs: d=%d outside 1..%d", d, kMaxDimGibbs);
-    std::vector<double> blob((size_t)(d + 4) * d + 2 * (size_t)d, 0.0);
-    for (int i = 0; i < d; ++i) {
-        double *r = blob.data() + (size_t)i * (d + 4);
-        for (int k = 0; k < d - 1; ++k) r[k] = p.P[(size_t)i * (d - 1) + k];
-        r[d - 1] = p.mu[i];
-        r[d] = p.sd[i];
-        r[d + 1] = 1.0 / p.sd[i];
-        r[d + 2] = p.lower[i];
-        r[d + 3] = p.upper[i];
-        blob[(size_t)(d + 4) * d + i] = p.mu[i];
-        blob[(size_t)(d + 4) * d + d + i] = p.init[i];
-    }
-    const bool moments = a.d_mean != nullptr;
+    if (d > kGibbsLaneMaxDim) return (size_t)d * ((d + kRowScalars + 1) & ~1) + d;
+    return (size_t)(d + 4) * d + 2 * (size_t)d;
+}
+
+static void build_gibbs_block(const GibbsParams &p, double *blk)
+{
+    const int d = p.d;
+    const size_t total = gibbs_block_doubles(d);
+    for (size_t e = 0; e < total; ++e) blk[e] = 0.0;
     if (d > kGibbsLaneMaxDim) { // wide variant: rows of W doubles, shared by the waves of a workgroup
         const int W = (d + kRowScalars + 1) & ~1;
-        std::vector<double> rows((size_t)d * W + d, 0.0);
         for (int i = 0; i < d; ++i) {
-            double *r = rows.data() + (size_t)i * W;
+            double *r = blk + (size_t)i * W;
             for (int k = 0, cidx = 0; k < d; ++k)
                 if (k != i) r[k] = p.P[(size_t)i * (d - 1) + cidx++];
             r[d] = p.mu[i];
@@ -435,7 +431,29 @@ int launch_gibbs(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipSt
             r[d + 4] = p.upper[i];
             r[d + 5] = std::fmin(std::fmax(p.mu[i], p.lower[i]), p.upper[i]); // moment shift: the point of the box nearest mu (finite)
         }
-        for (int k = 0; k < d; ++k) rows[(size_t)d * W + k] = p.init[k];
+        for (int k = 0; k < d; ++k) blk[(size_t)d * W + k] = p.init[k];
+        return;
+    }
+    for (int i = 0; i < d; ++i) {
+        double *r = blk + (size_t)i * (d + 4);
+        for (int k = 0; k < d - 1; ++k) r[k] = p.P[(size_t)i * (d - 1) + k];
+        r[d - 1] = p.mu[i];
+        r[d] = p.sd[i];
+        r[d + 1] = 1.0 / p.sd[i];
+        r[d + 2] = p.lower[i];
+        r[d + 3] = p.upper[i];
+        blk[(size_t)(d + 4) * d + i] = p.mu[i];
+        blk[(size_t)(d + 4) * d + d + i] = p.init[i];
+    }
+}
+
+// the launch proper, parameter block already on the device (and ordered before this launch on `s`)
+static int launch_gibbs_on_block(const GibbsArgs &a, bool tail_safe, const double *d_blk, hipStream_t s)
+{
+    const int d = a.d;
+    const bool moments = a.d_mean != nullptr;
+    if (d > kGibbsLaneMaxDim) {
+        const int W = (d + kRowScalars + 1) & ~1;
         // state in the dot waves' registers, 64 coordinates each; group and wave counts are functions of d only, so
         // that results do not depend on how chains are split over launches
         const int NDW = d <= kRegOwn ? 1 : (d <= 2 * kRegOwn ? 2 : 4); // dot waves per group
@@ -443,49 +461,127 @@ int launch_gibbs(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipSt
         const int threads = G * (1 + NDW) * 64;
         if ((W + threads - 1) / threads > kWideMaxPrefetch) return set_error(MCMC_E_UNSUPPORTED, "gibbs: d=%d too wide", d);
         const size_t ldsr = ((size_t)3 * (NDW * kRegOwn + kRegTail) + (size_t)G * (2 * (NDW + 1) * 64 + 128)) * sizeof(double);
-        double *d_rows = nullptr;
-        MCMC_HIP_CHECK(hipMallocAsync((void **)&d_rows, rows.size() * sizeof(double), s));
-        hipError_t ec = hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, s);
-        if (ec == hipSuccess) ec = hipStreamSynchronize(s); // rows is a local: do not let the copy outlive it
-        if (ec != hipSuccess) {
-            (void)hipFreeAsync(d_rows, s);
-            return set_error(MCMC_E_HIP, "gibbs: parameter upload failed: %s", hipGetErrorString(ec));
-        }
         const int64_t gridr = (a.n_chains + 64 * G - 1) / (64 * G);
         auto gor = [&](auto kern) -> int {
-            hipLaunchKernelGGL(kern, dim3((unsigned)gridr), dim3(threads), ldsr, s, a, (const double *)d_rows, W, G, NDW);
+            hipLaunchKernelGGL(kern, dim3((unsigned)gridr), dim3(threads), ldsr, s, a, d_blk, W, G, NDW);
             hipError_t el = hipGetLastError();
             return el == hipSuccess ? MCMC_OK : set_error(MCMC_E_HIP, "gibbs_reg_kernel launch failed: %s", hipGetErrorString(el));
         };
-        int rcr;
-        if (tail_safe)
-            rcr = moments ? gor(gibbs_reg_kernel<true, true>) : gor(gibbs_reg_kernel<true, false>);
-        else
-            rcr = moments ? gor(gibbs_reg_kernel<false, true>) : gor(gibbs_reg_kernel<false, false>);
-        hipError_t er = hipFreeAsync(d_rows, s);
-        if (rcr == MCMC_OK && er != hipSuccess) rcr = set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(er));
-        return rcr;
+        if (tail_safe) return moments ? gor(gibbs_reg_kernel<true, true>) : gor(gibbs_reg_kernel<true, false>);
+        return moments ? gor(gibbs_reg_kernel<false, true>) : gor(gibbs_reg_kernel<false, false>);
     }
-    double *d_prm = nullptr;
-    MCMC_HIP_CHECK(hipMallocAsync((void **)&d_prm, blob.size() * sizeof(double), s));
-    MCMC_HIP_CHECK(hipMemcpyAsync(d_prm, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    MCMC_HIP_CHECK(hipStreamSynchronize(s)); // blob is a local: do not let the copy outlive it
     const size_t lds = (size_t)d * 64 * sizeof(double);
     const int64_t grid = (a.n_chains + 63) / 64;
     auto go = [&](auto kern) -> int {
-        MCMC_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, s, a, (const double *)d_prm);
-        MCMC_HIP_CHECK(hipGetLastError());
-        return MCMC_OK;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, s, a, d_blk);
+        hipError_t el = hipGetLastError();
+        return el == hipSuccess ? MCMC_OK : set_error(MCMC_E_HIP, "gibbs_kernel launch failed: %s", hipGetErrorString(el));
     };
-    int rc;
-    if (tail_safe)
-        rc = moments ? go(gibbs_kernel<true, true>) : go(gibbs_kernel<true, false>);
-    else
-        rc = moments ? go(gibbs_kernel<false, true>) : go(gibbs_kernel<false, false>);
-    hipError_t e = hipFreeAsync(d_prm, s);
+    if (tail_safe) return moments ? go(gibbs_kernel<true, true>) : go(gibbs_kernel<true, false>);
+    return moments ? go(gibbs_kernel<false, true>) : go(gibbs_kernel<false, false>);
+}
+
+int launch_gibbs(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipStream_t s)
+{
+    const int d = a.d;
+    if (d < 1 || d > kMaxDimGibbs) return set_error(MCMC_E_UNSUPPORTED, "gibbs: d=%d outside 1..%d", d, kMaxDimGibbs);
+    std::vector<double> blk(gibbs_block_doubles(d));
+    build_gibbs_block(p, blk.data());
+    double *d_blk = nullptr;
+    MCMC_HIP_CHECK(hipMallocAsync((void **)&d_blk, blk.size() * sizeof(double), s));
+    hipError_t ec = hipMemcpyAsync(d_blk, blk.data(), blk.size() * sizeof(double), hipMemcpyHostToDevice, s);
+    if (ec == hipSuccess) ec = hipStreamSynchronize(s); // blk is a local: do not let the copy outlive it
+    if (ec != hipSuccess) {
+        (void)hipFreeAsync(d_blk, s);
+        return set_error(MCMC_E_HIP, "gibbs: parameter upload failed: %s", hipGetErrorString(ec));
+    }
+    int rc = launch_gibbs_on_block(a, tail_safe, d_blk, s);
+    hipError_t e = hipFreeAsync(d_blk, s);
     if (rc == MCMC_OK && e != hipSuccess) rc = set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e));
     return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// The no-allocation variant (mcmc_tmvn_gibbs_batch_noalloc): the parameter block lives in a file-scope device
+// array instead of a hipMallocAsync'ed buffer.  `g_gibbs_scratch` is a HOST-side stand-in for that array: its
+// device address is looked up once per device (each GPU holds its own copy at its own address) and only that
+// pointer is ever handed to a kernel.  The block reaches the array through the ARGUMENTS of small fill kernels
+// (kFillChunk doubles per launch): no host buffer has to outlive the call, nothing is allocated or synchronised, and
+// every launch is capturable.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU race.
+constexpr int kGibbsScratchDoubles = 20480; // 160 KB: the block of d = 128 is 17 280 doubles
+constexpr int kFillChunk = 448;             // 3 584 B of kernel arguments per fill launch
+constexpr int kMaxDevices = 16;
+static __device__ __align__(256) double g_gibbs_scratch[kGibbsScratchDoubles];
+
+struct FillChunk {
+    double v[kFillChunk];
+};
+__global__ __launch_bounds__(kFillChunk) void scratch_fill_kernel(double *__restrict__ dst, int count, const FillChunk c)
+{
+    const int t = threadIdx.x;
+    if (t < count) dst[t] = c.v[t];
+}
+
+// host staging of the block while it is cut into fill arguments: static like the device array (one per device, no
+// heap, no 160 KB stack frame), and like it shared by the calls on that device
+static double g_gibbs_stage[kMaxDevices][kGibbsScratchDoubles];
+
+// device address of g_gibbs_scratch on the CURRENT device, looked up once per device
+static int gibbs_scratch_ptr(double **out, int *dev_out)
+{
+    static std::mutex mu;
+    static double *ptrs[kMaxDevices] = {};
+    int dev = -1;
+    MCMC_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return set_error(MCMC_E_UNSUPPORTED, "no-allocation entry point: device index %d above %d", dev, kMaxDevices - 1);
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptrs[dev]) {
+        double *ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(g_gibbs_scratch));
+        if (e != hipSuccess || !ptr)
+            return set_error(MCMC_E_HIP, "hipGetSymbolAddress(scratch) failed on device %d: %s", dev, hipGetErrorString(e));
+        ptrs[dev] = ptr;
+    }
+    *out = ptrs[dev];
+    *dev_out = dev;
+    return MCMC_OK;
+}
+
+int gibbs_noalloc_max_dim() // largest d whose parameter block fits the scratch array
+{
+    int d = kGibbsLaneMaxDim;
+    while (d < kMaxDimGibbs && gibbs_block_doubles(d + 1) <= (size_t)kGibbsScratchDoubles) ++d;
+    return d;
+}
+
+int launch_gibbs_noalloc(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipStream_t s)
+{
+    const int d = a.d;
+    if (d < 1 || d > kMaxDimGibbs) return set_error(MCMC_E_UNSUPPORTED, "gibbs: d=%d outside 1..%d", d, kMaxDimGibbs);
+    const size_t total = gibbs_block_doubles(d);
+    if (total > (size_t)kGibbsScratchDoubles)
+        return set_error(MCMC_E_UNSUPPORTED,
+                         "mcmc_tmvn_gibbs_batch_noalloc: d=%d needs a parameter block of %zu doubles, the static scratch holds %d "
+                         "(d <= %d); use mcmc_tmvn_gibbs_batch",
+                         d, total, kGibbsScratchDoubles, gibbs_noalloc_max_dim());
+    double *ptr = nullptr;
+    int dev = 0;
+    int rc = gibbs_scratch_ptr(&ptr, &dev);
+    if (rc != MCMC_OK) return rc;
+    // the whole block of this call is written (padding included), so nothing of the previous call's contents is read
+    static_assert(sizeof(FillChunk) + 16 <= 4096, "fill arguments must stay inside 4 KB");
+    double *const blk = g_gibbs_stage[dev];
+    build_gibbs_block(p, blk);
+    for (size_t off = 0; off < total; off += kFillChunk) {
+        const int cnt = (int)(total - off < (size_t)kFillChunk ? total - off : (size_t)kFillChunk);
+        FillChunk c;
+        for (int t = 0; t < cnt; ++t) c.v[t] = blk[off + t];
+        for (int t = cnt; t < kFillChunk; ++t) c.v[t] = 0.0;
+        hipLaunchKernelGGL(scratch_fill_kernel, dim3(1), dim3(kFillChunk), 0, s, ptr + off, cnt, c);
+        hipError_t el = hipGetLastError();
+        if (el != hipSuccess) return set_error(MCMC_E_HIP, "scratch_fill_kernel launch failed: %s", hipGetErrorString(el));
+    }
+    return launch_gibbs_on_block(a, tail_safe, ptr, s);
 }
 
 int launch_gibbs_streams(uint64_t seed, int64_t chain_offset, int64_t n_chains, int32_t n_sweeps, int32_t d,
