@@ -147,7 +147,7 @@ typedef struct mcmc_rwm_config {
     int64_t chain_offset;          /* global id of local chain 0 (Philox counter)            */
     int32_t adapt_size_start;      /* 0 disables size adaptation  (:31,117)                  */
     int32_t adapt_shape_start;     /* 0 disables shape adaptation (:31,131)                  */
-    int32_t acceptance_window;     /* 0 = off; 1..64 supported on the device                 */
+    int32_t acceptance_window;     /* 0 = off; 1..65536 (above 64 the outcomes live in a per-chain ring in HBM) */
     int32_t thin;                  /* keep iteration i when i % thin == 0 (>= 1)             */
     double acceptance_rate_weight;
     double adapt_size_cooling;     /* reference default 0.99                                 */
@@ -156,7 +156,8 @@ typedef struct mcmc_rwm_config {
     int32_t rng_mode;              /* MCMC_RNG_PHILOX | MCMC_RNG_INJECTED                     */
     int32_t kernel;                /* MCMC_KERNEL_AUTO (0) | _LANE | _BLOCK | _PAIR: which device kernel runs */
     int32_t iter_offset;           /* resume: iterations already done (0 = fresh start). This call runs iterations
-                                      iter_offset+1 .. iter_offset+n_iterations and needs io->d_state_in         */
+                                      iter_offset+1 .. iter_offset+n_iterations and needs io->d_state_in;
+                                      iter_offset + n_iterations < 2^27 (the status word holds the iteration)   */
 } mcmc_rwm_config;
 
 typedef struct mcmc_rwm_io {
@@ -184,7 +185,8 @@ typedef struct mcmc_rwm_io {
     /* summary, may be NULL */
     int32_t *d_shape_iterations;   /* [n_chains] iterations whose proposal used scaling_sd^2 covmat_empirical (:131-139);
                                       counted from iteration 1, across resumed launches                   */
-    /* checkpoint / resume, each may be NULL: [mcmc_rwm_state_doubles(d)][n_chains] */
+    /* checkpoint / resume, each may be NULL: [mcmc_rwm_state_doubles_window(d, acceptance_window)][n_chains]
+       (= mcmc_rwm_state_doubles(d) rows unless acceptance_window > 64 with acceptance_rate_weight = 0) */
     const double *d_state_in;      /* chain state a previous call wrote (needs cfg->iter_offset = its end)  */
     double *d_state_out;           /* chain state after the last iteration of this call                     */
 } mcmc_rwm_io;
@@ -210,6 +212,9 @@ int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_config *cfg,
  * The array is plain doubles: copy it to the host and write it to disk to survive the process.
  */
 int64_t mcmc_rwm_state_doubles(int32_t d);
+/* The same with acceptance_window > 64 and acceptance_rate_weight = 0: the state then also carries the ring of
+ * outcomes (2 doubles per 64 outcomes) behind the mcmc_rwm_state_doubles(d) doubles above. */
+int64_t mcmc_rwm_state_doubles_window(int32_t d, int32_t acceptance_window);
 
 /* Fills the N(0,1) / U(0,1) arrays that mcmc_adapt_rwm_batch would draw in MCMC_RNG_PHILOX
  * mode for the same (seed, chain_offset, n_chains, n_iterations, d), in the d_Z / d_U layout

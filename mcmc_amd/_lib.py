@@ -96,6 +96,7 @@ SIGNATURES = {
     "mcmc_target_eval_batch": (C.c_int, [C.POINTER(McmcTarget), C.c_int32, C.c_int64, vp, vp, vp]),
     "mcmc_adapt_rwm_batch": (C.c_int, [C.POINTER(McmcTarget), C.POINTER(RwmConfig), C.POINTER(RwmIO), vp]),
     "mcmc_rwm_state_doubles": (C.c_int64, [C.c_int32]),
+    "mcmc_rwm_state_doubles_window": (C.c_int64, [C.c_int32, C.c_int32]),
     "mcmc_rwm_streams": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, vp, vp]),
     "mcmc_init_normal": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, C.c_int32, dp, C.c_double, vp, vp]),
     "mcmc_adaptMCMC": (C.c_int, [C.POINTER(McmcTarget), C.c_int32, dp, dp, C.c_int32, C.c_int32, C.c_double,

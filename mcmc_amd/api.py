@@ -328,8 +328,8 @@ def adapt_rwm_batch(target, n_chains, init_theta, covmat, n_iterations, adapt_si
     i0 = 0
     if resume is not None:
         i0 = int(resume.iterations)
-        if tuple(resume.array.shape) != (int(lib.mcmc_rwm_state_doubles(d)), n_chains):
-            raise ValueError("resume state has the wrong shape for this d / n_chains")
+        if tuple(resume.array.shape) != (_state_rows(d, acceptance_window, acceptance_rate_weight), n_chains):
+            raise ValueError("resume state has the wrong shape for this d / n_chains / acceptance_window")
     n_kept = (i0 + n) // int(thin) - i0 // int(thin)
 
     def buf(key, shape, dtype=f64, want=True):
@@ -380,12 +380,21 @@ def adapt_rwm_batch(target, n_chains, init_theta, covmat, n_iterations, adapt_si
     if resume is not None:
         io.d_state_in = _dev_ptr(resume.array, f64)
     if checkpoint:
-        state = torch.empty((int(lib.mcmc_rwm_state_doubles(d)), n_chains), dtype=f64, device=device)
+        state = torch.empty((_state_rows(d, acceptance_window, acceptance_rate_weight), n_chains), dtype=f64, device=device)
         io.d_state_out = _dev_ptr(state)
         out["state"] = RwmState(state, i0 + n)
     ct = t._c()
     check(lib.mcmc_adapt_rwm_batch(C.byref(ct), C.byref(cfg), C.byref(io), _stream_ptr()))
     return out
+
+
+def _state_rows(d, acceptance_window, acceptance_rate_weight):
+    """rows of a checkpoint: with a windowed rate over more than 64 outcomes the ring of outcomes rides along"""
+    w = int(acceptance_window) if float(acceptance_rate_weight) == 0.0 else 0
+    rows = int(lib.mcmc_rwm_state_doubles_window(int(d), w))
+    if rows < 0:
+        check(rows)
+    return rows
 
 
 @dataclass

@@ -8,6 +8,7 @@
 #include <limits>
 #include <string>
 
+#include "accept_window.h"
 #include "common.h"
 #include "host_linalg.h"
 #include "targets.h"
@@ -132,8 +133,9 @@ extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_co
     if (cfg->adapt_size_start < 0 || cfg->adapt_shape_start < 0)
         return set_error(MCMC_E_BAD_ARG, "adapt_size_start / adapt_shape_start must be >= 0");
     if (cfg->acceptance_window < 0) return set_error(MCMC_E_BAD_ARG, "acceptance_window must be >= 0");
-    if (cfg->acceptance_window > 64)
-        return set_error(MCMC_E_UNSUPPORTED, "acceptance_window=%d: the device keeps at most 64 outcomes", cfg->acceptance_window);
+    if (cfg->acceptance_window > kMaxAcceptanceWindow)
+        return set_error(MCMC_E_UNSUPPORTED, "acceptance_window=%d: the device keeps at most %d outcomes per chain", cfg->acceptance_window,
+                         kMaxAcceptanceWindow);
     if (std::isnan(cfg->acceptance_rate_weight) || std::isnan(cfg->adapt_size_cooling) || std::isnan(cfg->max_scaling_sd))
         return set_error(MCMC_E_BAD_ARG, "NaN in the adaptation parameters");
     if (!io->h_covmat) return set_error(MCMC_E_BAD_ARG, "h_covmat is NULL");
@@ -146,8 +148,10 @@ extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_co
     if (d > kMaxDimRwm) return set_error(MCMC_E_UNSUPPORTED, "adaptive RWM: d=%d above the limit %d", d, kMaxDimRwm);
     if (cfg->kernel < MCMC_KERNEL_AUTO || cfg->kernel > MCMC_KERNEL_PAIR)
         return set_error(MCMC_E_BAD_ARG, "unknown kernel choice %d", cfg->kernel);
-    if (cfg->iter_offset < 0 || (int64_t)cfg->iter_offset + cfg->n_iterations > 0x7fffffff)
-        return set_error(MCMC_E_BAD_ARG, "iter_offset=%d out of range", cfg->iter_offset);
+    // the status word is (iteration << 4) | code in 32 bits
+    if (cfg->iter_offset < 0 || (int64_t)cfg->iter_offset + cfg->n_iterations >= (1 << 27))
+        return set_error(MCMC_E_BAD_ARG, "iter_offset + n_iterations = %lld: must stay below 2^27 (the per-chain status word holds the iteration in 27 bits)",
+                         (long long)cfg->iter_offset + cfg->n_iterations);
     if ((cfg->iter_offset > 0) != (io->d_state_in != nullptr))
         return set_error(MCMC_E_BAD_ARG, "resume needs both iter_offset > 0 and d_state_in (a fresh start neither)");
     if (cfg->kernel == MCMC_KERNEL_LANE && d > kMaxLaneDimRwm)
@@ -197,16 +201,38 @@ extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_co
     a.d_state_in = io->d_state_in;
     a.d_state_out = io->d_state_out;
 
-    // pow(adapt_size_cooling, i - adapt_size_start) for i = iter_offset + (0..n) (adaptMCMC_source.cpp:123), host libm
+    // per-call device scratch: the cooling table and, for acceptance_window > 64, the outcome ring; both are released
+    // on every path out of this function
     double *d_cool = nullptr;
+    unsigned long long *d_ring = nullptr;
+    auto release = [&](int code) {
+        for (void *ptr : {(void *)d_cool, (void *)d_ring}) {
+            if (!ptr) continue;
+            hipError_t e = hipFreeAsync(ptr, s);
+            if (code == MCMC_OK && e != hipSuccess) code = set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e));
+        }
+        return code;
+    };
+    // pow(adapt_size_cooling, i - adapt_size_start) for i = iter_offset + (0..n) (adaptMCMC_source.cpp:123), host libm
     if (cfg->adapt_size_start != 0) {
         std::vector<double> cool((size_t)cfg->n_iterations + 1);
         for (int i = 0; i <= cfg->n_iterations; ++i)
             cool[i] = std::pow(cfg->adapt_size_cooling, cfg->iter_offset + i - cfg->adapt_size_start);
-        MCMC_HIP_CHECK(hipMallocAsync((void **)&d_cool, cool.size() * sizeof(double), s));
-        MCMC_HIP_CHECK(hipMemcpyAsync(d_cool, cool.data(), cool.size() * sizeof(double), hipMemcpyHostToDevice, s));
-        MCMC_HIP_CHECK(hipStreamSynchronize(s)); // `cool` is a local: do not let the copy outlive it
+        hipError_t e = hipMallocAsync((void **)&d_cool, cool.size() * sizeof(double), s);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_cool, cool.data(), cool.size() * sizeof(double), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s); // `cool` is a local: do not let the copy outlive it
+        if (e != hipSuccess) return release(set_error(MCMC_E_HIP, "cooling table upload failed: %s", hipGetErrorString(e)));
         a.d_cool_pow = d_cool;
+    }
+    a.win_words = cfg->acceptance_rate_weight == 0 ? accept_window_words(cfg->acceptance_window) : 0;
+    if (a.win_words > 0) {
+        const size_t bytes = (size_t)a.win_words * (size_t)cfg->n_chains * sizeof(unsigned long long);
+        hipError_t e = hipMallocAsync((void **)&d_ring, bytes, s);
+        if (e == hipSuccess) e = hipMemsetAsync(d_ring, 0, bytes, s);
+        if (e != hipSuccess)
+            return release(set_error(MCMC_E_HIP, "acceptance_window=%d: no room for the outcome rings (%zu bytes): %s", cfg->acceptance_window,
+                                     bytes, hipGetErrorString(e)));
+        a.d_win_ring = d_ring;
     }
     if (use_block)
         rc = launch_rwm_block(a, p, s);
@@ -214,17 +240,21 @@ extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_co
         rc = launch_rwm_pair(a, p, s);
     else
         rc = launch_rwm_lane(a, p, s);
-    if (d_cool) {
-        hipError_t e = hipFreeAsync(d_cool, s);
-        if (rc == MCMC_OK && e != hipSuccess) rc = set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e));
-    }
-    return rc;
+    return release(rc);
 }
 
 extern "C" int64_t mcmc_rwm_state_doubles(int32_t d)
 {
     if (d < 1 || d > kMaxDimRwm) return set_error(MCMC_E_BAD_ARG, "mcmc_rwm_state_doubles: d=%d outside 1..%d", d, kMaxDimRwm);
     return rwm_state_layout(d).TOTAL;
+}
+
+extern "C" int64_t mcmc_rwm_state_doubles_window(int32_t d, int32_t acceptance_window)
+{
+    if (d < 1 || d > kMaxDimRwm) return set_error(MCMC_E_BAD_ARG, "mcmc_rwm_state_doubles_window: d=%d outside 1..%d", d, kMaxDimRwm);
+    if (acceptance_window < 0 || acceptance_window > kMaxAcceptanceWindow)
+        return set_error(MCMC_E_BAD_ARG, "mcmc_rwm_state_doubles_window: acceptance_window=%d outside 0..%d", acceptance_window, kMaxAcceptanceWindow);
+    return rwm_state_layout(d).TOTAL + 2 * accept_window_words(acceptance_window);
 }
 
 extern "C" int mcmc_rwm_streams(uint64_t seed, int64_t chain_offset, int64_t n_chains, int32_t n_iterations,
@@ -380,8 +410,9 @@ static int tmvn_gibbs_batch_impl(const mcmc_gibbs_config *cfg, const mcmc_gibbs_
     if (cfg->n_sweeps < 1) return set_error(MCMC_E_BAD_ARG, "n_sweeps must be >= 1");
     if (cfg->thin < 1) return set_error(MCMC_E_BAD_ARG, "thin must be >= 1");
     if (cfg->burn < 0) return set_error(MCMC_E_BAD_ARG, "burn must be >= 0");
-    if (cfg->sweep_offset < 0 || (int64_t)cfg->sweep_offset + cfg->n_sweeps > 0x7fffffff)
-        return set_error(MCMC_E_BAD_ARG, "sweep_offset=%d out of range", cfg->sweep_offset);
+    if (cfg->sweep_offset < 0 || (int64_t)cfg->sweep_offset + cfg->n_sweeps >= (1 << 27))
+        return set_error(MCMC_E_BAD_ARG, "sweep_offset + n_sweeps = %lld: must stay below 2^27 (the per-chain status word holds the sweep in 27 bits)",
+                         (long long)cfg->sweep_offset + cfg->n_sweeps);
     if (!io->h_mu || !io->h_sigma || !io->h_lower || !io->h_upper) return set_error(MCMC_E_BAD_ARG, "mu/sigma/lower/upper missing");
     if (!io->h_init_state && !io->d_init) return set_error(MCMC_E_BAD_ARG, "need h_init_state or d_init");
     if ((io->d_mean == nullptr) != (io->d_m2 == nullptr)) return set_error(MCMC_E_BAD_ARG, "d_mean and d_m2 come as a pair");

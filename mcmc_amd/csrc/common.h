@@ -112,6 +112,9 @@ struct RwmArgs {
     int32_t iter_offset;
     const double *d_state_in;
     double *d_state_out;
+    // acceptance_window > 64 (accept_window.h): the outcome ring, [win_words][n_chains] 64-bit words, zeroed by the host
+    unsigned long long *d_win_ring;
+    int32_t win_words;
 };
 
 #ifndef __HIPCC_RTC__
@@ -163,11 +166,14 @@ enum RwmStateScalar {
     ST_TCUR,      // target(theta_current)
     ST_RATE, ST_SD, ST_MULT, // acceptance_rate, scaling_sd, scaling_multiplier
     ST_SEFF, ST_PRODR, ST_ROOT, // scale kept apart from R, prod diag(R), 1/sqrt((2 pi)^d det)
-    ST_WLO, ST_WHI, ST_WLEN,    // acceptance window: 64 outcomes as two 32-bit halves, and its length
+    ST_WLO, ST_WHI, ST_WLEN,    // acceptance window: 64 outcomes (window > 64: the ring word in use) as two 32-bit halves, and its length
     ST_BASE,      // 1 when R factors covmat_empirical
-    ST_STATUS, ST_NSHAPE, ST_RESERVED,
+    ST_STATUS, ST_NSHAPE,
+    ST_WCOUNT,    // acceptance window > 64: accepted outcomes held
     kRwmStateScalars
 };
+// With acceptance_window > 64 the state continues behind TOTAL with the outcome ring: word w as two 32-bit halves at
+// TOTAL + 2 w, TOTAL + 2 w + 1 (mcmc_rwm_state_doubles_window).
 struct RwmStateLayout {
     int THETA, MEAN, C, R, S, TOTAL;
 };

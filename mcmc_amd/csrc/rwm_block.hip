@@ -33,6 +33,7 @@
 #include <algorithm>
 #endif
 
+#include "accept_window.h"
 #include "common.h"
 #include "philox.h"
 #include "targets.h"
@@ -245,8 +246,9 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
     double s_eff = 1.0;    // covmat_proposal = s_eff^2 R^T R
     double t_cur = target(th);
     double rate = 0.0, scaling_sd = 1.0, scaling_multiplier = 1.0;
-    uint64_t win_bits = 0;
-    int win_len = 0;
+    AcceptWindow win; // replicated in every thread, like the other scalars of the chain; thread 0 stores the ring words
+    int win_pos = accept_window_pos(i0, window);
+    unsigned long long *const ring = a.d_win_ring ? a.d_win_ring + c : nullptr;
     int32_t status = MCMC_CHAIN_OK, n_shape = 0;
     bool dead = false;
     const RwmStateLayout SL = rwm_state_layout(d);
@@ -274,8 +276,12 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
         s_eff = ss[ST_SEFF * n];
         prodR = ss[ST_PRODR * n];
         rootTerm = ss[ST_ROOT * n];
-        win_bits = ((uint64_t)(uint32_t)ss[ST_WHI * n] << 32) | (uint64_t)(uint32_t)ss[ST_WLO * n];
-        win_len = (int)ss[ST_WLEN * n];
+        win.bits = ((uint64_t)(uint32_t)ss[ST_WHI * n] << 32) | (uint64_t)(uint32_t)ss[ST_WLO * n];
+        win.len = (int)ss[ST_WLEN * n];
+        win.count = (int)ss[ST_WCOUNT * n];
+        for (int wd = tid; wd < a.win_words; wd += kBlockThreads) // the outcome ring (acceptance_window > 64) follows the scalars
+            ring[(int64_t)wd * n] = ((uint64_t)(uint32_t)sp[(int64_t)(SL.TOTAL + 2 * wd + 1) * n] << 32) |
+                                    (uint64_t)(uint32_t)sp[(int64_t)(SL.TOTAL + 2 * wd) * n];
         base_emp = ss[ST_BASE * n] != 0.0;
         status = (int32_t)ss[ST_STATUS * n];
         n_shape = (int32_t)ss[ST_NSHAPE * n];
@@ -505,10 +511,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             if (window == 0) {
                 rate = add_rn(rate, div_rn(add_rn(acc, -rate), di));
             } else {
-                win_bits = (win_bits << 1) | (accept ? 1ull : 0ull);
-                if (win_len < window) ++win_len;
-                const uint64_t msk = (win_len >= 64) ? ~0ull : ((1ull << win_len) - 1ull);
-                rate = div_rn((double)__popcll(win_bits & msk), (double)win_len);
+                rate = accept_window_push(win, accept, window, win_pos, ring, n, tid == 0);
             }
         } else {
             rate = add_rn(mul_rn(rate, 1 - wgt), mul_rn(acc, wgt));
@@ -601,13 +604,20 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             ss[ST_SEFF * n] = s_eff;
             ss[ST_PRODR * n] = prodR;
             ss[ST_ROOT * n] = rootTerm;
-            ss[ST_WLO * n] = (double)(uint32_t)win_bits;
-            ss[ST_WHI * n] = (double)(uint32_t)(win_bits >> 32);
-            ss[ST_WLEN * n] = (double)win_len;
+            ss[ST_WLO * n] = (double)(uint32_t)win.bits;
+            ss[ST_WHI * n] = (double)(uint32_t)(win.bits >> 32);
+            ss[ST_WLEN * n] = (double)win.len;
             ss[ST_BASE * n] = base_emp ? 1.0 : 0.0;
             ss[ST_STATUS * n] = (double)status;
             ss[ST_NSHAPE * n] = (double)n_shape;
-            ss[ST_RESERVED * n] = 0.0;
+            ss[ST_WCOUNT * n] = (double)win.count;
+        }
+        __syncthreads(); // thread 0's last ring store is complete (the barrier drains its vector-memory counter)
+        for (int wd = tid; wd < a.win_words; wd += kBlockThreads) {
+            const uint64_t v = (wd == (win_pos >> 6)) ? win.bits
+                                                      : (uint64_t)__hip_atomic_load(ring + (int64_t)wd * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sp[(int64_t)(SL.TOTAL + 2 * wd) * n] = (double)(uint32_t)v;
+            sp[(int64_t)(SL.TOTAL + 2 * wd + 1) * n] = (double)(uint32_t)(v >> 32);
         }
     }
 }

@@ -23,6 +23,7 @@
 // The acceptance-rate recurrences (:188-207) and the phase tests (:117,131) are evaluated
 // with the reference's exact operation sequence (no FMA contraction), because they feed
 // discrete decisions.
+#include "accept_window.h"
 #include "common.h"
 #include "philox.h"
 #include "targets.h"
@@ -90,8 +91,9 @@ __global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const dou
     double rootTerm = sh[Lay::ROOT0];
     double t_cur = Target<KIND, D>::eval(theta, PrmView{sh + Lay::TPRM});
     double rate = 0.0, scaling_sd = 1.0, scaling_multiplier = 1.0;
-    uint64_t win_bits = 0;
-    int win_len = 0;
+    AcceptWindow win;
+    int win_pos = accept_window_pos(i0, window); // wave-uniform: every chain is at the same iteration
+    unsigned long long *const ring = a.d_win_ring ? a.d_win_ring + cc : nullptr;
     int32_t status = MCMC_CHAIN_OK, n_shape = 0;
     bool dead = false;
     constexpr RwmStateLayout SL = rwm_state_layout(D);
@@ -113,8 +115,13 @@ __global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const dou
         scaling_sd = ss[ST_SD * n];
         scaling_multiplier = ss[ST_MULT * n];
         rootTerm = ss[ST_ROOT * n];
-        win_bits = ((uint64_t)(uint32_t)ss[ST_WHI * n] << 32) | (uint64_t)(uint32_t)ss[ST_WLO * n];
-        win_len = (int)ss[ST_WLEN * n];
+        win.bits = ((uint64_t)(uint32_t)ss[ST_WHI * n] << 32) | (uint64_t)(uint32_t)ss[ST_WLO * n];
+        win.len = (int)ss[ST_WLEN * n];
+        win.count = (int)ss[ST_WCOUNT * n];
+        if (live)
+            for (int wd = 0; wd < a.win_words; ++wd) // the outcome ring (acceptance_window > 64) follows the scalars
+                ring[(int64_t)wd * n] = ((uint64_t)(uint32_t)sp[(int64_t)(SL.TOTAL + 2 * wd + 1) * n] << 32) |
+                                        (uint64_t)(uint32_t)sp[(int64_t)(SL.TOTAL + 2 * wd) * n];
         status = (int32_t)ss[ST_STATUS * n];
         n_shape = (int32_t)ss[ST_NSHAPE * n];
         dead = status != MCMC_CHAIN_OK;
@@ -258,10 +265,7 @@ __global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const dou
             if (window == 0) {
                 rate = add_rn(rate, div_rn(add_rn(acc, -rate), di));
             } else {
-                win_bits = (win_bits << 1) | (accept ? 1ull : 0ull);
-                if (win_len < window) ++win_len;
-                const uint64_t m = (win_len >= 64) ? ~0ull : ((1ull << win_len) - 1ull);
-                rate = div_rn((double)__popcll(win_bits & m), (double)win_len);
+                rate = accept_window_push(win, accept, window, win_pos, ring, n, live);
             }
         } else {
             rate = add_rn(mul_rn(rate, 1 - w), mul_rn(acc, w));
@@ -335,13 +339,19 @@ __global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const dou
             ss[ST_SEFF * n] = 1.0;
             ss[ST_PRODR * n] = 1.0;
             ss[ST_ROOT * n] = rootTerm;
-            ss[ST_WLO * n] = (double)(uint32_t)win_bits;
-            ss[ST_WHI * n] = (double)(uint32_t)(win_bits >> 32);
-            ss[ST_WLEN * n] = (double)win_len;
+            ss[ST_WLO * n] = (double)(uint32_t)win.bits;
+            ss[ST_WHI * n] = (double)(uint32_t)(win.bits >> 32);
+            ss[ST_WLEN * n] = (double)win.len;
             ss[ST_BASE * n] = 0.0;
             ss[ST_STATUS * n] = (double)status;
             ss[ST_NSHAPE * n] = (double)n_shape;
-            ss[ST_RESERVED * n] = 0.0;
+            ss[ST_WCOUNT * n] = (double)win.count;
+            for (int wd = 0; wd < a.win_words; ++wd) {
+                const uint64_t v = (wd == (win_pos >> 6)) ? win.bits
+                                                          : (uint64_t)__hip_atomic_load(ring + (int64_t)wd * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sp[(int64_t)(SL.TOTAL + 2 * wd) * n] = (double)(uint32_t)v;
+                sp[(int64_t)(SL.TOTAL + 2 * wd + 1) * n] = (double)(uint32_t)(v >> 32);
+            }
         }
     }
 }

@@ -566,7 +566,7 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
             ss[ST_BASE * n] = base_emp ? 1.0 : 0.0;
             ss[ST_STATUS * n] = (double)(sync_ok ? status : (MCMC_CHAIN_SYNC_LOST | ((i0 + n_iter) << 4)));
             ss[ST_NSHAPE * n] = (double)n_shape;
-            ss[ST_RESERVED * n] = 0.0;
+            ss[ST_WCOUNT * n] = 0.0; // windows above 64 outcomes run in the one-wave kernel (rwm_pair_serves)
         }
     }
 }
@@ -631,13 +631,15 @@ bool rwm_pair_serves(const RwmArgs &a)
 {
     const bool full = a.d_Z || a.d_sigma_trace || a.d_accepted || a.d_log_acceptance || a.d_log_A || a.d_scaling_sd ||
                       a.d_scaling_multiplier || a.d_rate_trace;
-    return !full && a.d >= 1 && a.d <= kMaxPairDimRwm;
+    // a window of more than 64 outcomes needs the ring of accept_window.h: two more live values in a sampler wave that
+    // already spills; those runs go to the one-wave kernel
+    return !full && a.d >= 1 && a.d <= kMaxPairDimRwm && a.win_words == 0;
 }
 
 int launch_rwm_pair(const RwmArgs &a, const RwmParams &p, hipStream_t s)
 {
     if (!rwm_pair_serves(a))
-        return set_error(MCMC_E_UNSUPPORTED, "paired-wave kernel: Philox streams, no per-iteration diagnostics, d <= %d",
+        return set_error(MCMC_E_UNSUPPORTED, "paired-wave kernel: Philox streams, no per-iteration diagnostics, d <= %d, acceptance_window <= 64",
                          kMaxPairDimRwm);
     if (p.target_kind == MCMC_TARGET_USER) return launch_rwm_pair_user(a, p, s);
     if (p.target_kind == MCMC_TARGET_GOLDSTEIN_PRICE) {

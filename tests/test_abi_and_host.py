@@ -108,7 +108,7 @@ def test_validation_happens_before_any_gpu_work():
     cov2 = (C.c_double * 4)(1.0, 2.0, 2.0, 1.0)  # not positive definite
     io.h_covmat = cov2
     assert lib.mcmc_adapt_rwm_batch(C.byref(tgt), C.byref(cfg), C.byref(io), None) == _lib.MCMC_E_NOT_PD
-    cfg.acceptance_window = 65
+    cfg.acceptance_window = 65537
     assert lib.mcmc_adapt_rwm_batch(C.byref(tgt), C.byref(cfg), C.byref(io), None) == _lib.MCMC_E_UNSUPPORTED
     cfg.acceptance_window = 0
     cfg.thin = 0

@@ -128,6 +128,71 @@ def test_three_acceptance_rate_modes(cuda, tag, w, win):
     assert _rel(out["theta_trace"].cpu().numpy()[:, :, 0], g[f"trace_{tag}"]) < RTOL
 
 
+@pytest.mark.parametrize("d,win,kernel", [(3, 200, "lane"), (3, 1000, "lane"), (5, 65, "lane"), (20, 130, "block"), (4, 64, "lane")])
+def test_acceptance_window_beyond_one_word(cuda, oracle, d, win, kernel):
+    """adaptMCMC_source.cpp:194-203 takes ANY window: above 64 outcomes the device keeps them in a per-chain ring
+    (accept_window.h).  The rate is an exact small-integer quotient, so its trace must equal the oracle's bit for bit --
+    before the ring fills, across word boundaries, through the wrap (several times), for windows that are not a
+    multiple of 64 -- and with it the phase switches and the trajectory."""
+    import mcmc_amd
+
+    rng = np.random.default_rng(600 + win + d)
+    nc, n = 3, 2600
+    Sig, H = _gauss(d, 0.6)
+    init = rng.standard_normal((d, nc))
+    Z = rng.standard_normal((n, d, nc))
+    U = rng.random((n, nc))
+    cov0 = (0.3 if d < 10 else 0.05) * np.eye(d)
+    ass, ashs = (30 if d < 10 else 0), (400 if d < 10 else 600)
+    out = mcmc_amd.adapt_rwm_batch(mcmc_amd.Target.gaussian(np.zeros(d), H), nc, cuda.tensor(init, device="cuda"), cov0, n, ass, 0.0,
+                                   win, ashs, Z=cuda.tensor(Z, device="cuda"), U=cuda.tensor(U, device="cuda"), diagnostics=True,
+                                   kernel=kernel)
+    cuda.cuda.synchronize()
+    assert np.all(out["status"].cpu().numpy() == 0)
+    for c in range(nc):
+        ref = oracle.adaptMCMC(oracle.gaussian_target(np.zeros(d), H), init[:, c], cov0, n, ass, 0.0, win, ashs, Z[:, :, c], U[:, c],
+                               diagnostics=True, store_sigma=False)
+        assert _check_decisions(out["accepted"].cpu().numpy()[:, c], ref["diag"]) == 0
+        np.testing.assert_array_equal(out["rate_trace"].cpu().numpy()[:, c], ref["diag"]["acceptance_rate"])
+        np.testing.assert_allclose(out["scaling_sd"].cpu().numpy()[:, c], ref["diag"]["scaling_sd"], rtol=1e-12)
+        assert _rel(out["theta_trace"].cpu().numpy()[:, :, c], ref["theta_trace"]) < (RTOL if kernel == "lane" else BLOCK_RTOL)
+        assert out["acceptance_rate"].cpu().numpy()[c] == ref["acceptance_rate"]
+
+
+def test_large_window_philox_auto_kernel_sharding_and_resume(cuda, oracle):
+    """Philox run with a 300-outcome window: AUTO must not pick the paired-wave kernel (its window is one word), the
+    run replays through the oracle, does not depend on sharding, and a run split in three -- with the ring of
+    outcomes riding in the checkpoint -- equals the uninterrupted one bit for bit (also for the per-workgroup kernel)."""
+    import mcmc_amd
+
+    for d, nc, n, cov in ((4, 130, 1500, 0.5), (16, 6, 900, 0.08)):
+        Sig, H = _gauss(d, 0.5)
+        tgt = mcmc_amd.Target.gaussian(np.zeros(d), H)
+        kw = dict(seed=13, chain_offset=40)
+        ad = (25, 0.0, 300, 350)
+        whole = mcmc_amd.adapt_rwm_batch(tgt, nc, np.ones(d), cov * np.eye(d), n, *ad, **kw)
+        assert np.all(whole["status"].cpu().numpy() == 0)
+        Z, U = mcmc_amd.rwm_streams(13, nc, n, d, chain_offset=40)
+        for c in (0, nc - 1):
+            ref = oracle.adaptMCMC(oracle.gaussian_target(np.zeros(d), H), np.ones(d), cov * np.eye(d), n, *ad, Z.cpu().numpy()[:, :, c],
+                                   U.cpu().numpy()[:, c], store_sigma=False)
+            assert _rel(whole["theta_trace"].cpu().numpy()[:, :, c], ref["theta_trace"]) < BLOCK_RTOL
+            assert whole["acceptance_rate"].cpu().numpy()[c] == ref["acceptance_rate"]
+        part = mcmc_amd.adapt_rwm_batch(tgt, nc - 3, np.ones(d), cov * np.eye(d), n, *ad, seed=13, chain_offset=43)
+        assert cuda.equal(part["theta_trace"], whole["theta_trace"][:, :, 3:])
+        a = mcmc_amd.adapt_rwm_batch(tgt, nc, np.ones(d), cov * np.eye(d), 150, *ad, checkpoint=True, **kw)      # ring not full yet
+        b = mcmc_amd.adapt_rwm_batch(tgt, nc, np.ones(d), cov * np.eye(d), 517, *ad, checkpoint=True, resume=a["state"], **kw)
+        c3 = mcmc_amd.adapt_rwm_batch(tgt, nc, np.ones(d), cov * np.eye(d), n - 667, *ad, resume=b["state"], **kw)
+        got = cuda.cat([a["theta_trace"], b["theta_trace"], c3["theta_trace"]])
+        assert cuda.equal(got, whole["theta_trace"])
+        assert cuda.equal(c3["acceptance_rate"], whole["acceptance_rate"])
+    with pytest.raises(mcmc_amd.McmcError):
+        mcmc_amd.adapt_rwm_batch(tgt, 4, np.ones(d), np.eye(d), 10, 0, 0.0, 65537, 0)  # beyond the ring's limit
+    with pytest.raises(mcmc_amd.McmcError):
+        mcmc_amd.adapt_rwm_batch(mcmc_amd.Target.gaussian(np.zeros(3), np.eye(3)), 4, np.ones(3), np.eye(3), 10, 5, 0.0, 100, 0,
+                                 kernel="pair")  # refused, not silently rerouted
+
+
 def test_nan_and_minus_inf_reject_paths(cuda):
     """Far jump: exp(-q/2) underflows, p = -Inf, la = NaN, `log(A) < NaN` is false -> reject.
     Overflowing target: -Inf -> immediate reject (adaptMCMC_source.cpp:163-171)."""
