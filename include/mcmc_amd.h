@@ -65,7 +65,10 @@ extern "C" {
 
 /* ----- kernel choice for the Metropolis path ----------------------------------------- */
 #define MCMC_KERNEL_AUTO 0   /* one chain per lane for d <= mcmc_amd_max_lane_dim() (the paired-wave variant when it
-                                serves the request), else per workgroup                             */
+                                serves the request), else per workgroup.  The two per-lane kernels round differently
+                                (1e-12 relative), so under AUTO asking for a diagnostics array can change the low bits of
+                                a trace; a resumed AUTO run returns to the kernel that wrote the checkpoint, or is
+                                refused with MCMC_E_UNSUPPORTED when that kernel cannot serve the call        */
 #define MCMC_KERNEL_LANE 1   /* one chain per lane (register-resident state), d <= 12               */
 #define MCMC_KERNEL_BLOCK 2  /* one chain per 256-thread workgroup (LDS-resident factor), d <= 128,
                                 Gaussian target only                                               */

@@ -234,9 +234,26 @@ extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_co
                                      bytes, hipGetErrorString(e)));
         a.d_win_ring = d_ring;
     }
+    // AUTO picks between the two one-chain-per-lane kernels by what the call asks for (diagnostics, injected streams and
+    // windows above 64 outcomes need the one-wave kernel).  A checkpoint is in its writer's representation, so a resumed
+    // AUTO run goes back to the kernel named in the state, or is refused here if that kernel cannot serve the request.
+    bool use_pair = cfg->kernel == MCMC_KERNEL_PAIR || (cfg->kernel == MCMC_KERNEL_AUTO && rwm_pair_serves(a));
+    if (cfg->kernel == MCMC_KERNEL_AUTO && !use_block && a.d_state_in) {
+        double tag = 0.0;
+        const RwmStateLayout SL = rwm_state_layout(d);
+        hipError_t e = hipMemcpyAsync(&tag, a.d_state_in + (int64_t)(SL.S + ST_TAG) * cfg->n_chains, sizeof(double), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return release(set_error(MCMC_E_HIP, "reading the checkpoint's kernel tag failed: %s", hipGetErrorString(e)));
+        if (tag == (double)MCMC_KERNEL_PAIR && !use_pair)
+            return release(set_error(MCMC_E_UNSUPPORTED,
+                                     "this checkpoint was written by the paired-wave kernel, which cannot serve this call (per-iteration "
+                                     "diagnostics, injected streams, sigma_empirical trace or acceptance_window > 64): resume with the outputs "
+                                     "of the run that wrote it, or run both parts with kernel = MCMC_KERNEL_LANE"));
+        if (tag == (double)MCMC_KERNEL_LANE) use_pair = false;
+    }
     if (use_block)
         rc = launch_rwm_block(a, p, s);
-    else if (cfg->kernel == MCMC_KERNEL_PAIR || (cfg->kernel == MCMC_KERNEL_AUTO && rwm_pair_serves(a)))
+    else if (use_pair)
         rc = launch_rwm_pair(a, p, s);
     else
         rc = launch_rwm_lane(a, p, s);

@@ -148,3 +148,25 @@ def test_gibbs_split_run_equals_uninterrupted_run(cuda, d, thin, tail):
     assert int((whole["status"] != 0).sum()) == 0
     assert cuda.equal(cuda.cat([a["trace"], b["trace"]], dim=0), whole["trace"])
     assert cuda.equal(b["final_state"], whole["final_state"])
+
+
+def test_auto_resume_returns_to_the_kernel_that_wrote_the_state(cuda):
+    """AUTO picks the paired-wave kernel for a plain Philox run and the one-wave kernel when diagnostics are asked for;
+    a checkpoint is in its writer's representation.  A resumed AUTO run therefore goes back to the writer -- the lane
+    kernel's state continues under AUTO without diagnostics -- and a pair-kernel state resumed WITH diagnostics is
+    refused on the host instead of stopping every chain with MCMC_CHAIN_BAD_STATE."""
+    import mcmc_amd
+
+    d, nc = 4, 100
+    tgt = mcmc_amd.Target.gaussian(np.zeros(d), np.eye(d))
+    ad = (10, 0.0, 0, 40)
+    kw = dict(seed=3)
+    whole = mcmc_amd.adapt_rwm_batch(tgt, nc, np.ones(d), np.eye(d), 300, *ad, kernel="lane", **kw)
+    a = mcmc_amd.adapt_rwm_batch(tgt, nc, np.ones(d), np.eye(d), 120, *ad, checkpoint=True, diagnostics=True, **kw)   # AUTO -> lane
+    b = mcmc_amd.adapt_rwm_batch(tgt, nc, np.ones(d), np.eye(d), 180, *ad, resume=a["state"], **kw)                   # AUTO, no diagnostics
+    assert int((b["status"] != 0).sum()) == 0
+    assert cuda.equal(cuda.cat([a["theta_trace"], b["theta_trace"]]), whole["theta_trace"])
+    p = mcmc_amd.adapt_rwm_batch(tgt, nc, np.ones(d), np.eye(d), 120, *ad, checkpoint=True, **kw)                      # AUTO -> pair
+    with pytest.raises(mcmc_amd.McmcError) as e:
+        mcmc_amd.adapt_rwm_batch(tgt, nc, np.ones(d), np.eye(d), 180, *ad, resume=p["state"], diagnostics=True, **kw)
+    assert e.value.code == -2 and "paired-wave" in str(e.value)

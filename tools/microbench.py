@@ -74,10 +74,20 @@ def rwm_block(d, chains, iters, ass=1, ashs=0, thin=10):
     f = lambda: mcmc_amd.adapt_rwm_batch(tgt, chains, np.zeros(d), 0.01 * np.eye(d), iters, ass, 0.0, 0, ashs, seed=1, thin=thin,
                                          final=False)
     ms = timeit(f, reps=2)
+    out = f()
     rate = chains * iters / (ms * 1e-3)
-    fl = d ** 3 / 3 + 4.5 * d * d + 8.5 * d
-    print(f"rwm-block d={d} chains={chains} iters={iters} ass={ass}: {ms:.2f} ms  {rate:.3e} chain-iter/s  {rate*fl/1e12:.2f} TF alg "
-          f"({rate*fl/78.6e12*100:.1f}% of FP64 peak)")
+    # 4.5 d^2 + 8.5 d per iteration, + d^3/3 only for the iterations that factor covmat_empirical
+    # (the shape phase; the size phase keeps the unscaled factor and does no factorization)
+    shape = float(out["shape_iterations"].double().sum().item())
+    fl = (chains * iters * (4.5 * d * d + 8.5 * d) + shape * d ** 3 / 3) / (ms * 1e-3)
+    print(f"rwm-block d={d} chains={chains} iters={iters} ass={ass}: {ms:.2f} ms  {rate:.3e} chain-iter/s  {fl/1e12:.2f} TF alg "
+          f"({fl/78.6e12*100:.1f}% of FP64 peak; shape-phase fraction {shape/(chains*iters):.2f})")
+
+
+if __name__ == "__main__" and "mid" in sys.argv:  # the 12 < d < 64 range
+    for d in (11, 13, 16, 24, 32, 48, 63):
+        rwm_block(d, 32768, 300)
+        rwm_block_shape(d, 16384, 600)
 
 
 if __name__ == "__main__" and "block" in sys.argv:
@@ -102,7 +112,9 @@ def rwm_block_shape(d, chains, iters):
     out = f()
     frac = float(out["shape_iterations"].double().mean().item()) / iters
     bad = int((out["status"] != 0).sum().item())
-    print(f"rwm-block-shape d={d} chains={chains} iters={iters}: {ms:.2f} ms  {chains*iters/(ms*1e-3):.3e} chain-iter/s  shape fraction {frac:.2f}  failed {bad}")
+    fl = chains * iters * (4.5 * d * d + 8.5 * d + frac * d ** 3 / 3) / (ms * 1e-3)
+    print(f"rwm-block-shape d={d} chains={chains} iters={iters}: {ms:.2f} ms  {chains*iters/(ms*1e-3):.3e} chain-iter/s  shape fraction {frac:.2f}  "
+          f"{fl/1e12:.2f} TF alg ({fl/78.6e12*100:.1f}% of FP64 peak)  failed {bad}")
 
 
 if __name__ == "__main__" and "shape" in sys.argv:
