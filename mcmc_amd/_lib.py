@@ -30,6 +30,7 @@ MCMC_KERNEL_AUTO = 0
 MCMC_KERNEL_LANE = 1
 MCMC_KERNEL_BLOCK = 2
 MCMC_KERNEL_PAIR = 3
+MCMC_KERNEL_ROW = 4
 
 MCMC_TARGET_GAUSSIAN_PREC = 0
 MCMC_TARGET_GOLDSTEIN_PRICE = 1

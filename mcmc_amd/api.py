@@ -349,7 +349,7 @@ def adapt_rwm_batch(target, n_chains, init_theta, covmat, n_iterations, adapt_si
                       seed=int(seed) & 0xFFFFFFFFFFFFFFFF,
                       rng_mode=L.MCMC_RNG_INJECTED if Z is not None else L.MCMC_RNG_PHILOX,
                       kernel={"auto": L.MCMC_KERNEL_AUTO, "lane": L.MCMC_KERNEL_LANE, "block": L.MCMC_KERNEL_BLOCK,
-                              "pair": L.MCMC_KERNEL_PAIR}[kernel],
+                              "pair": L.MCMC_KERNEL_PAIR, "row": L.MCMC_KERNEL_ROW}[kernel],
                       iter_offset=i0)
     if (Z is None) != (U is None):
         raise ValueError("give both Z and U, or neither")

@@ -146,7 +146,7 @@ extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_co
         return set_error(MCMC_E_BAD_ARG, "unknown rng_mode %d", cfg->rng_mode);
     }
     if (d > kMaxDimRwm) return set_error(MCMC_E_UNSUPPORTED, "adaptive RWM: d=%d above the limit %d", d, kMaxDimRwm);
-    if (cfg->kernel < MCMC_KERNEL_AUTO || cfg->kernel > MCMC_KERNEL_PAIR)
+    if (cfg->kernel < MCMC_KERNEL_AUTO || cfg->kernel > MCMC_KERNEL_ROW)
         return set_error(MCMC_E_BAD_ARG, "unknown kernel choice %d", cfg->kernel);
     // the status word is (iteration << 4) | code in 32 bits
     if (cfg->iter_offset < 0 || (int64_t)cfg->iter_offset + cfg->n_iterations >= (1 << 27))
@@ -156,7 +156,9 @@ extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_co
         return set_error(MCMC_E_BAD_ARG, "resume needs both iter_offset > 0 and d_state_in (a fresh start neither)");
     if (cfg->kernel == MCMC_KERNEL_LANE && d > kMaxLaneDimRwm)
         return set_error(MCMC_E_UNSUPPORTED, "one-chain-per-lane kernel: d=%d above its limit %d", d, kMaxLaneDimRwm);
-    const bool use_block = cfg->kernel == MCMC_KERNEL_BLOCK || (cfg->kernel == MCMC_KERNEL_AUTO && d > kMaxLaneDimRwm);
+    if (cfg->kernel == MCMC_KERNEL_ROW && d > kMaxRowDimRwm)
+        return set_error(MCMC_E_UNSUPPORTED, "one-chain-per-row kernel: d=%d above its limit %d", d, kMaxRowDimRwm);
+    bool use_block = cfg->kernel == MCMC_KERNEL_BLOCK || (cfg->kernel == MCMC_KERNEL_AUTO && d > kMaxLaneDimRwm);
     if (use_block && target->kind != MCMC_TARGET_GAUSSIAN_PREC && target->kind != MCMC_TARGET_USER)
         return set_error(MCMC_E_UNSUPPORTED, "the per-workgroup kernel (d > %d) serves the Gaussian target and user targets only", kMaxLaneDimRwm);
 
@@ -237,8 +239,24 @@ extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_co
     // AUTO picks between the two one-chain-per-lane kernels by what the call asks for (diagnostics, injected streams and
     // windows above 64 outcomes need the one-wave kernel).  A checkpoint is in its writer's representation, so a resumed
     // AUTO run goes back to the kernel named in the state, or is refused here if that kernel cannot serve the request.
-    bool use_pair = cfg->kernel == MCMC_KERNEL_PAIR || (cfg->kernel == MCMC_KERNEL_AUTO && rwm_pair_serves(a));
-    if (cfg->kernel == MCMC_KERNEL_AUTO && !use_block && a.d_state_in) {
+    // 12 < d <= 32: one chain per 16 / 32 lanes where that kernel serves the call (Philox, no diagnostics), else per workgroup
+    bool use_row = cfg->kernel == MCMC_KERNEL_ROW || (cfg->kernel == MCMC_KERNEL_AUTO && use_block && rwm_row_serves(a, target->kind));
+    if (cfg->kernel == MCMC_KERNEL_AUTO && use_block && a.d_state_in) { // a checkpoint goes back to its writer
+        double tag = 0.0;
+        const RwmStateLayout SL = rwm_state_layout(d);
+        hipError_t e = hipMemcpyAsync(&tag, a.d_state_in + (int64_t)(SL.S + ST_TAG) * cfg->n_chains, sizeof(double), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return release(set_error(MCMC_E_HIP, "reading the checkpoint's kernel tag failed: %s", hipGetErrorString(e)));
+        if (tag == (double)MCMC_KERNEL_ROW && !use_row)
+            return release(set_error(MCMC_E_UNSUPPORTED,
+                                     "this checkpoint was written by the one-chain-per-row kernel, which cannot serve this call (per-iteration "
+                                     "diagnostics, injected streams or sigma_empirical trace): resume with the outputs of the run that wrote "
+                                     "it, or run both parts with kernel = MCMC_KERNEL_BLOCK"));
+        if (tag == (double)MCMC_KERNEL_BLOCK) use_row = false;
+    }
+    if (use_row) use_block = false;
+    bool use_pair = !use_row && (cfg->kernel == MCMC_KERNEL_PAIR || (cfg->kernel == MCMC_KERNEL_AUTO && rwm_pair_serves(a)));
+    if (cfg->kernel == MCMC_KERNEL_AUTO && !use_block && !use_row && a.d_state_in) {
         double tag = 0.0;
         const RwmStateLayout SL = rwm_state_layout(d);
         hipError_t e = hipMemcpyAsync(&tag, a.d_state_in + (int64_t)(SL.S + ST_TAG) * cfg->n_chains, sizeof(double), hipMemcpyDeviceToHost, s);
@@ -251,7 +269,9 @@ extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_co
                                      "of the run that wrote it, or run both parts with kernel = MCMC_KERNEL_LANE"));
         if (tag == (double)MCMC_KERNEL_LANE) use_pair = false;
     }
-    if (use_block)
+    if (use_row)
+        rc = launch_rwm_row(a, p, s);
+    else if (use_block)
         rc = launch_rwm_block(a, p, s);
     else if (use_pair)
         rc = launch_rwm_pair(a, p, s);

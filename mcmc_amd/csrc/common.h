@@ -27,6 +27,8 @@ constexpr int kMaxDimGibbs = 256;
 // 1.79e9 against 1.66e9 chain-sweeps/s, d = 28 1.40e9 against 1.43e9, d = 32 1.10e9 against 1.26e9)
 constexpr int kGibbsLaneMaxDim = 27;
 constexpr int kMaxDimRwm = 128;
+// largest d of the one-chain-per-row kernel (a chain on 16 or 32 lanes of a wavefront, rwm_row.hip)
+constexpr int kMaxRowDimRwm = 32;
 
 #ifndef __HIPCC_RTC__
 int set_error(int code, const char *fmt, ...);
@@ -139,6 +141,8 @@ using RwmLauncher = std::function<hipError_t(int variant, unsigned grid, unsigne
 int launch_rwm_lane(const RwmArgs &a, const RwmParams &p, hipStream_t s);
 int launch_rwm_block(const RwmArgs &a, const RwmParams &p, hipStream_t s);
 bool rwm_pair_serves(const RwmArgs &a);
+bool rwm_row_serves(const RwmArgs &a, int target_kind);
+int launch_rwm_row(const RwmArgs &a, const RwmParams &p, hipStream_t s);
 int launch_rwm_pair(const RwmArgs &a, const RwmParams &p, hipStream_t s);
 int launch_rwm_streams(uint64_t seed, int64_t chain_offset, int64_t n_chains, int32_t n_iterations,
                        int32_t d, double *d_Z, double *d_U, hipStream_t s);

@@ -1,0 +1,548 @@
+// Adaptive random-walk Metropolis for 12 < d <= 32: one chain per ROW of 16 (d <= 16) or 32 lanes (gfx950).
+//
+// Replaces the main loop of adaptMCMC / rwMCMC (adaptMCMC_source.cpp:108-216, :252-313) in the range where the chain
+// state no longer fits one lane (the factor R and covmat_empirical are 136 doubles each at d = 16, 528 at d = 32) but
+// a 256-thread workgroup per chain leaves > 90 % of the lanes idle (d = 16 ran 60 x slower than d = 10).
+//
+// Layout.  Lane j of a row owns COORDINATE j of its chain: theta_j, theta_mean_j, Y_j, and COLUMN j of the two
+// matrices -- R_kj (upper factor, zero below the diagonal) and covmat_empirical_kj (the full symmetric column) -- in
+// L registers each, statically indexed.  Four chains (d <= 16) or two (d <= 32) share a wavefront.  Everything a
+// chain needs from "the other coordinates" is one cross-lane primitive:
+//     v_fmac_f64_dpp acc, x, y row_newbcast:k      acc += (x of lane k of this 16-lane row) * y
+// one instruction at the FP64 FMA rate (tools/ubench_r2.hip), so a matrix-vector product is L instructions:
+//     proposal   theta_j + s sum_k Y_k R_kj                      (:153-154, terms in the reference's order)
+//     target     -0.5 sum_j v_j sum_k H_jk v_k                   (the row of H from LDS, shared by all chains)
+//     update     C_kj = C_kj (i-1)/i + ((i-1)/i^2 r_k) r_j       (update_sigma, :42-45)
+//     Cholesky   right-looking, in place in the R registers: at pivot p every lane scales its entry of row p, and
+//                the trailing update a_ij -= R_pi R_pj is one such instruction per remaining row i
+// For 32-lane rows the operand is first spread over both 16-lane halves by v_permlane16_swap_b32 (two instructions
+// give "lanes 0-15 of the chain in both halves" and "lanes 16-31 in both halves").  Scalars of a chain (acceptance
+// rate, scaling_sd, target value, ...) are computed redundantly, bit-identically, in every lane of its row.
+//
+// chol(s^2 Sigma) = s chol(Sigma): as in the other kernels R is the UNSCALED factor and the scale is kept apart,
+// so size-phase iterations do no factorization.
+//
+// Trace: lane j holds coordinate j, so a store instruction of a wave would touch 8 bytes in each of 16 x 4 lines.
+// The 16 (8) chains of a workgroup are consecutive; each kept iteration goes through a double-buffered LDS tile
+// [k][chain] and leaves as whole 128-byte (64-byte) runs, one LDS-only barrier per kept iteration.
+//
+// Serves Philox runs without per-iteration diagnostics (the per-workgroup kernel of rwm_block.hip carries injected
+// streams, the sigma_empirical trace and diagnostics for d > 12); Gaussian target.
+#include "accept_window.h"
+#include "common.h"
+#include "philox.h"
+#include "targets.h"
+
+namespace mcmc {
+
+template <int V>
+struct RowIC {
+    static constexpr int value = V;
+};
+template <int K, int N, class F>
+__device__ __forceinline__ void row_unroll(F &&f)
+{
+    if constexpr (K < N) {
+        f(RowIC<K>{});
+        row_unroll<K + 1, N>(f);
+    }
+}
+
+// A VGPR written by a VALU instruction must not be read through DPP for two wait states.  The compiler keeps that
+// rule for its own DPP instructions but cannot see into the asm below, so every value that is about to become a DPP
+// operand passes through this fence once: the s_nop sits behind the instruction that produced x and ahead of every
+// later use of it.
+__device__ __forceinline__ double dpp_ready(double x)
+{
+    asm volatile("s_nop 1" : "+v"(x));
+    return x;
+}
+
+// acc += (x of lane K of this lane's 16-lane row) * y      (x: a dpp_ready value)
+template <int K>
+__device__ __forceinline__ void fmac_rb(double &acc, double x, double y)
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(K));
+}
+// x of lane K of this lane's 16-lane row
+template <int K>
+__device__ __forceinline__ double row_bcast(double x)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(x);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, 0x150 + K, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), 0x150 + K, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+// A value per lane of a chain's row, made available to every lane of the row: for 16-lane rows the value itself, for
+// 32-lane rows two registers, `lo` = the values of lanes 0-15 of the chain in both halves, `hi` = those of lanes 16-31.
+template <int L>
+struct RowVec;
+template <>
+struct RowVec<16> {
+    double lo;
+    __device__ __forceinline__ explicit RowVec(double x) : lo(dpp_ready(x)) {}
+    template <int K>
+    __device__ __forceinline__ void fmac(double &acc, double y) const { fmac_rb<K>(acc, lo, y); }
+    template <int K>
+    __device__ __forceinline__ double get() const { return row_bcast<K>(lo); }
+};
+template <>
+struct RowVec<32> {
+    double lo, hi;
+    __device__ __forceinline__ explicit RowVec(double x)
+    {
+        const uint64_t u = (uint64_t)__double_as_longlong(x);
+        const auto a = __builtin_amdgcn_permlane16_swap((uint32_t)u, (uint32_t)u, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap((uint32_t)(u >> 32), (uint32_t)(u >> 32), false, false);
+        lo = __longlong_as_double((long long)(((uint64_t)b[0] << 32) | a[0]));
+        hi = __longlong_as_double((long long)(((uint64_t)b[1] << 32) | a[1]));
+        asm volatile("s_nop 1" : "+v"(lo), "+v"(hi));
+    }
+    template <int K>
+    __device__ __forceinline__ void fmac(double &acc, double y) const
+    {
+        if constexpr (K < 16)
+            fmac_rb<K>(acc, lo, y);
+        else
+            fmac_rb<K - 16>(acc, hi, y);
+    }
+    template <int K>
+    __device__ __forceinline__ double get() const
+    {
+        if constexpr (K < 16)
+            return row_bcast<K>(lo);
+        else
+            return row_bcast<K - 16>(hi);
+    }
+};
+
+// sum over the lanes of a chain's row, the same bits in every lane: four DPP steps inside a 16-lane row (the pairs are
+// symmetric, and IEEE addition is commutative), then the two halves of a 32-lane row
+template <int L>
+__device__ __forceinline__ double row_sum(double x)
+{
+    auto dpp_add = [](double y, auto ctrl) -> double {
+        constexpr int C = decltype(ctrl)::value;
+        const uint64_t b = (uint64_t)__double_as_longlong(y);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, C, 0xf, 0xf, false);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), C, 0xf, 0xf, false);
+        return y + __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+    };
+    x = dpp_add(x, RowIC<0xB1>{});  // quad_perm [1,0,3,2]: lane ^ 1
+    x = dpp_add(x, RowIC<0x4E>{});  // quad_perm [2,3,0,1]: lane ^ 2
+    x = dpp_add(x, RowIC<0x141>{}); // row_half_mirror: the other quad of the same half row
+    x = dpp_add(x, RowIC<0x140>{}); // row_mirror: the other half of the row
+    if constexpr (L == 32) {
+        const RowVec<32> v(x);
+        x = v.lo + v.hi;
+    }
+    return x;
+}
+
+// parameter block (doubles), staged in LDS: min diag(covmat), prod diag(R0), -, -, tmean[L], init[L],
+// Hs[k][j] = (H_jk + H_kj) / 2 (zero beyond d), R0c[k][j] = chol(covmat)_kj for k <= j < d (zero elsewhere)
+template <int L>
+struct RowLayout {
+    static constexpr int MINVAR = 0, PROD0 = 1, TMEAN = 4, INIT = 4 + L, HS = 4 + 2 * L, R0 = HS + L * L, TOTAL = R0 + L * L;
+    static constexpr int CPW = 256 / L; // chains per workgroup
+    static constexpr int lds_doubles(int d) { return TOTAL + 2 * d * CPW; }
+};
+
+template <int L, bool STATE>
+__global__ __launch_bounds__(256, L == 16 ? 3 : 2) void rwm_row_kernel(const RwmArgs a, const double *__restrict__ prm)
+{
+    using Lay = RowLayout<L>;
+    constexpr int CPW = Lay::CPW, RPW = 64 / L;
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & (L - 1);       // this lane's coordinate
+    const int cl = wave * RPW + lane / L; // this lane's chain inside the workgroup
+    const int d = a.d;
+    const bool act = j < d;
+    const int64_t n = a.n_chains;
+    const int64_t c0 = (int64_t)blockIdx.x * CPW, c = c0 + cl;
+    const bool live = c < n;
+    const int64_t cc = live ? c : n - 1; // rows past the end shadow the last chain and store nothing
+    const uint64_t gchain = (uint64_t)(a.chain_offset + cc);
+    const PhiloxKey key(a.seed);
+    const int ass = a.adapt_size_start, ashs = a.adapt_shape_start;
+    const int window = a.acceptance_window;
+    const double wgt = a.acceptance_rate_weight;
+    const bool need_moments = ashs != 0 || a.d_final_mean || a.d_final_cov || (STATE && (a.d_state_in || a.d_state_out));
+    const int i0 = STATE ? a.iter_offset : 0;
+
+    for (int e = tid; e < Lay::TOTAL; e += 256) lds[e] = prm[e];
+    __syncthreads();
+    const double *const Hs = lds + Lay::HS + j;   // H_jk at Hs[k * L]
+    const double *const R0c = lds + Lay::R0 + j;  // chol(covmat)_kj at R0c[k * L]
+    double *const stage = lds + Lay::TOTAL;       // [2][d][CPW] trace tile
+    const double tm = lds[Lay::TMEAN + j];
+    const double min_var = lds[Lay::MINVAR], prodR0 = lds[Lay::PROD0];
+
+    double Rc[L], Cc[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        Rc[k] = R0c[k * L];
+        Cc[k] = 0.0;
+    }
+    double theta = act ? (a.d_init ? a.d_init[(int64_t)j * n + cc] : lds[Lay::INIT + j]) : tm; // padding: v = theta - m = 0
+    double mean = theta;
+
+    // -0.5 (x - m)^T H (x - m), the same bits in every lane of the row
+    auto target = [&](double x) -> double {
+        const double v = x - tm;
+        const RowVec<L> vv(v);
+        double g = 0.0;
+        row_unroll<0, L>([&](auto kc) {
+            constexpr int K = decltype(kc)::value;
+            vv.template fmac<K>(g, Hs[K * L]);
+        });
+        return -0.5 * row_sum<L>(v * g);
+    };
+
+    double prodR = prodR0;
+    bool base_emp = false; // R holds chol(covmat_empirical)
+    double s_eff = 1.0;    // covmat_proposal = s_eff^2 R^T R
+    double rootTerm, sq_unused;
+    fm_sqrt_rsq(a.twopi_pow_d * (prodR * prodR), sq_unused, rootTerm);
+    double t_cur = target(theta);
+    double rate = 0.0, scaling_sd = 1.0;
+    AcceptWindow win;
+    int win_pos = accept_window_pos(i0, window);
+    unsigned long long *const ring = a.d_win_ring ? a.d_win_ring + cc : nullptr;
+    int32_t status = MCMC_CHAIN_OK, n_shape = 0;
+    bool dead = false;
+    const RwmStateLayout SL = rwm_state_layout(d);
+    if (STATE && a.d_state_in) { // resume: everything the loop carries from one iteration to the next
+        const double *const sp = a.d_state_in + cc;
+        if (act) {
+            theta = sp[(int64_t)(SL.THETA + j) * n];
+            mean = sp[(int64_t)(SL.MEAN + j) * n];
+        }
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            if (act && k < d) { // column j of the symmetric covmat_empirical from its packed upper triangle; of R the part k <= j
+                Cc[k] = sp[(int64_t)(SL.C + (k <= j ? tri(k, j) : tri(j, k))) * n];
+                Rc[k] = k <= j ? sp[(int64_t)(SL.R + tri(k, j)) * n] : 0.0;
+            }
+        }
+        const double *const ss = sp + (int64_t)SL.S * n;
+        t_cur = ss[ST_TCUR * n];
+        rate = ss[ST_RATE * n];
+        scaling_sd = ss[ST_SD * n];
+        s_eff = ss[ST_SEFF * n];
+        prodR = ss[ST_PRODR * n];
+        rootTerm = ss[ST_ROOT * n];
+        win.bits = ((uint64_t)(uint32_t)ss[ST_WHI * n] << 32) | (uint64_t)(uint32_t)ss[ST_WLO * n];
+        win.len = (int)ss[ST_WLEN * n];
+        win.count = (int)ss[ST_WCOUNT * n];
+        if (live && j == 0)
+            for (int wd = 0; wd < a.win_words; ++wd)
+                ring[(int64_t)wd * n] = ((uint64_t)(uint32_t)sp[(int64_t)(SL.TOTAL + 2 * wd + 1) * n] << 32) |
+                                        (uint64_t)(uint32_t)sp[(int64_t)(SL.TOTAL + 2 * wd) * n];
+        base_emp = ss[ST_BASE * n] != 0.0;
+        status = (int32_t)ss[ST_STATUS * n];
+        n_shape = (int32_t)ss[ST_NSHAPE * n];
+        dead = status != MCMC_CHAIN_OK;
+        if (ss[ST_TAG * n] != (double)MCMC_KERNEL_ROW || ss[ST_ITER * n] != (double)i0) { // not a state this launch can continue
+            dead = true;
+            status = ((i0 + 1) << 4) | MCMC_CHAIN_BAD_STATE;
+            theta = __builtin_nan("");
+        }
+    }
+
+    int next_keep = (i0 / a.thin + 1) * a.thin; // next iteration whose state is stored
+    int64_t t_kept = 0;
+    for (int i = i0 + 1; i <= i0 + a.n_iterations; ++i) {
+        const int li = i - i0; // position inside this launch (cooling table)
+        const double di = (double)i;
+        // ---- adaptation of covmat_proposal (adaptMCMC_source.cpp:117-139), replicated ------------------
+        bool rescale = false, refactor = false;
+        if (ass != 0 && i >= ass && (ashs == 0 || mul_rn(rate, di) < (double)ashs)) {
+            const double scaling_multiplier = fm_exp(a.d_cool_pow[li] * (rate - 0.234));
+            scaling_sd = mul_rn(scaling_sd, scaling_multiplier);
+            scaling_sd = (a.max_scaling_sd < scaling_sd) ? a.max_scaling_sd : scaling_sd;
+            const double s2 = mul_rn(scaling_sd, scaling_sd);
+            const bool any_small = mul_rn(s2, min_var) < 2E-16; // the smallest variance decides the test at :126
+            rescale = !any_small && !dead;                     // covmat_proposal = scaling_sd^2 covmat (:129)
+        } else if (ashs != 0 && mul_rn(rate, di) >= (double)ashs) {
+            scaling_sd = a.shape_scaling_sd;
+            refactor = !dead; // covmat_proposal = scaling_sd^2 covmat_empirical (:138)
+            ++n_shape;
+        }
+        if (rescale) {
+            if (base_emp) { // back from the shape phase: the factor of covmat again
+#pragma unroll
+                for (int k = 0; k < L; ++k) Rc[k] = R0c[k * L];
+                prodR = prodR0;
+                base_emp = false;
+            }
+            s_eff = scaling_sd;
+        }
+        // ---- R = chol(covmat_empirical) (:153): right-looking, in place in the R registers, one pivot at a time --
+        // A divergent branch: the lanes of a row belong to one chain and take it together, so every cross-lane
+        // operand comes from an active lane; the rows of chains that do not factor sit it out.
+        if (refactor) {
+            double (&Ac)[L] = Rc;
+#pragma unroll
+            for (int k = 0; k < L; ++k) Ac[k] = Cc[k];
+            bool ok = true;
+            double prod = 1.0;
+            row_unroll<0, L>([&](auto pc) {
+                constexpr int P = decltype(pc)::value;
+                if (P < d) { // uniform
+                    const RowVec<L> rowp(Ac[P]); // row p of the trailing matrix: entry j in lane j
+                    const double piv = rowp.template get<P>();
+                    ok = ok && (piv > 0.0);
+                    double rjj, rinv;
+                    fm_sqrt_rsq(piv, rjj, rinv);
+                    prod *= rjj;
+                    // finished row p of R: R_pj = a_pj / sqrt(a_pp) for j > p, the root itself at j = p, zero for j < p
+                    const double rp = (j > P) ? Ac[P] * rinv : (j == P ? rjj : 0.0);
+                    Ac[P] = rp;
+                    if constexpr (P + 1 < L) {
+                        const double nrp = -rp;
+                        const RowVec<L> rv(nrp);
+                        row_unroll<P + 1, L>([&](auto ic) { // a_ij -= R_pi R_pj; only the part i <= j is ever read
+                            constexpr int I = decltype(ic)::value;
+                            rv.template fmac<I>(Ac[I], rp);
+                        });
+                    }
+                }
+            });
+#pragma unroll
+            for (int k = 0; k < L; ++k) Rc[k] = (k < d && act) ? Ac[k] : 0.0; // the padding stays zero
+            prodR = prod;
+            base_emp = true;
+            s_eff = scaling_sd;
+            if (!ok) { // arma::chol throws here; the chain stops and reports where
+                dead = true;
+                status = (i << 4) | MCMC_CHAIN_CHOL_FAILED;
+                theta = __builtin_nan("");
+            }
+        }
+        if (rescale || refactor) { // 1 / sqrt((2 pi)^d det(covmat_proposal)) (:56)
+            double sp = 1.0, b = s_eff;
+            for (int e = d; e > 0; e >>= 1) { // s_eff^d by repeated squaring
+                if (e & 1) sp *= b;
+                b *= b;
+            }
+            const double dt = sp * prodR;
+            double det = dt * dt;
+            if (!(det > 1e-280 && det < 1e280)) {
+                // near under / overflow: the running product of the LU diagonal s^2 R_kk^2, factor by factor, as
+                // arma::det forms it (see rwm_block.hip: when it reaches 0 decides when the reference starts to
+                // reject everything through the NaN of :169-175)
+                double rd = 0.0;
+#pragma unroll
+                for (int k = 0; k < L; ++k) rd = (k == j) ? Rc[k] : rd;
+                const RowVec<L> dv(rd);
+                const double s2 = mul_rn(s_eff, s_eff);
+                det = 1.0;
+                row_unroll<0, L>([&](auto kc) {
+                    constexpr int K = decltype(kc)::value;
+                    if (K < d) {
+                        const double rkk = dv.template get<K>();
+                        det = mul_rn(det, mul_rn(s2, mul_rn(rkk, rkk)));
+                    }
+                });
+            }
+            fm_sqrt_rsq(a.twopi_pow_d * det, sq_unused, rootTerm);
+        }
+
+        // ---- draws: this lane's normal, the chain's uniform (:149-152,174) ----------------------------------
+        double z0, z1, u0, u1;
+        philox_normal2(key, gchain, (uint32_t)i, TAG_RWM_NORMAL, (uint32_t)(j >> 1), z0, z1);
+        const double Y = act ? ((j & 1) ? z1 : z0) : 0.0;
+        philox_uniform2(key, gchain, (uint32_t)i, TAG_RWM_UNIFORM, 0u, u0, u1);
+        const double logA = fm_log<true>(u0);
+
+        // ---- proposal theta + s (Y R) (:153-154) and |Y|^2 for the Hastings term --------------------------------
+        const RowVec<L> yv(Y);
+        double yr = 0.0;
+        row_unroll<0, L>([&](auto kc) {
+            constexpr int K = decltype(kc)::value;
+            yv.template fmac<K>(yr, Rc[K]);
+        });
+        const double prop = theta + s_eff * yr;
+        const double q = row_sum<L>(Y * Y);
+
+        // ---- target and Metropolis-Hastings log ratio (:157-171) ------------------------------------------------
+        const double t_prop = target(prop);
+        double la;
+        if (!isfinite(t_prop)) {
+            la = -__builtin_inf();
+        } else {
+            la = t_prop - t_cur;
+            const double p = fm_log<true>(rootTerm * fm_exp(-0.5 * q));
+            la = add_rn(la, p);
+            la = add_rn(la, -p);
+        }
+        const bool accept = logA < la;
+        if (accept) {
+            theta = prop;
+            t_cur = t_prop;
+        }
+
+        // ---- trace (:185): through the LDS tile, whole runs of consecutive chains per coordinate -----------------
+        if (i == next_keep) { // uniform over the workgroup
+            if (a.d_trace) {
+                double *const tile = stage + (t_kept & 1) * (d * CPW);
+                if (act) tile[j * CPW + cl] = theta;
+                lds_barrier();
+                double *const row = a.d_trace + t_kept * d * n + c0;
+                for (int e = tid; e < d * CPW; e += 256) {
+                    const int k = e / CPW, q2 = e - k * CPW;
+                    if (c0 + q2 < n) row[(int64_t)k * n + q2] = tile[e];
+                }
+            }
+            next_keep += a.thin;
+            ++t_kept;
+        }
+
+        // ---- acceptance rate (:188-207), replicated ------------------------------------------------------------
+        const double acc = accept ? 1.0 : 0.0;
+        if (i == 1) {
+            rate = acc;
+        } else if (wgt == 0) {
+            if (window == 0)
+                rate = add_rn(rate, div_rn(add_rn(acc, -rate), di));
+            else
+                rate = accept_window_push(win, accept, window, win_pos, ring, n, live && j == 0);
+        } else {
+            rate = add_rn(mul_rn(rate, 1 - wgt), mul_rn(acc, wgt));
+        }
+
+        // ---- running mean / covariance (:210-214, update_sigma :42-45) ----------------------------------------
+        if (need_moments) {
+            const double inv_i = fm_rcp(di);
+            const double sfac = (di - 1.0) * inv_i; // C (i-1)/i + ((i-1)/i^2 r_k) r_j
+            const double res = act ? theta - mean : 0.0;
+            mean += res * inv_i;
+            const RowVec<L> bv((sfac * inv_i) * res);
+            row_unroll<0, L>([&](auto kc) {
+                constexpr int K = decltype(kc)::value;
+                double v = Cc[K] * sfac;
+                bv.template fmac<K>(v, res);
+                Cc[K] = v;
+            });
+        }
+    }
+
+    if (live && act) {
+        if (a.d_final_theta) a.d_final_theta[(int64_t)j * n + c] = theta;
+        if (a.d_final_mean) a.d_final_mean[(int64_t)j * n + c] = mean;
+        if (a.d_final_cov) { // the upper triangle, mirrored: the entries k > j of a lane's column are the same numbers up to
+                             // rounding ((f r_k) r_j against (f r_j) r_k) and are never read -- the factorization uses k <= j
+#pragma unroll
+            for (int k = 0; k < L; ++k) {
+                if (k <= j) {
+                    a.d_final_cov[(int64_t)(j * d + k) * n + c] = Cc[k];
+                    a.d_final_cov[(int64_t)(k * d + j) * n + c] = Cc[k];
+                }
+            }
+        }
+    }
+    if (live && j == 0) {
+        if (a.d_acceptance_rate) a.d_acceptance_rate[c] = rate;
+        if (a.d_status) a.d_status[c] = status;
+        if (a.d_shape_iterations) a.d_shape_iterations[c] = n_shape;
+    }
+    if (STATE && a.d_state_out && live) {
+        double *const sp = a.d_state_out + c;
+        if (act) {
+            sp[(int64_t)(SL.THETA + j) * n] = theta;
+            sp[(int64_t)(SL.MEAN + j) * n] = mean;
+#pragma unroll
+            for (int k = 0; k < L; ++k) {
+                if (k <= j) {
+                    sp[(int64_t)(SL.C + tri(k, j)) * n] = Cc[k];
+                    sp[(int64_t)(SL.R + tri(k, j)) * n] = Rc[k];
+                }
+            }
+        }
+        if (j == 0) {
+            double *const ss = sp + (int64_t)SL.S * n;
+            ss[ST_TAG * n] = (double)MCMC_KERNEL_ROW;
+            ss[ST_ITER * n] = (double)(i0 + a.n_iterations);
+            ss[ST_TCUR * n] = t_cur;
+            ss[ST_RATE * n] = rate;
+            ss[ST_SD * n] = scaling_sd;
+            ss[ST_MULT * n] = 1.0;
+            ss[ST_SEFF * n] = s_eff;
+            ss[ST_PRODR * n] = prodR;
+            ss[ST_ROOT * n] = rootTerm;
+            ss[ST_WLO * n] = (double)(uint32_t)win.bits;
+            ss[ST_WHI * n] = (double)(uint32_t)(win.bits >> 32);
+            ss[ST_WLEN * n] = (double)win.len;
+            ss[ST_BASE * n] = base_emp ? 1.0 : 0.0;
+            ss[ST_STATUS * n] = (double)status;
+            ss[ST_NSHAPE * n] = (double)n_shape;
+            ss[ST_WCOUNT * n] = (double)win.count;
+            for (int wd = 0; wd < a.win_words; ++wd) {
+                const uint64_t v = (wd == (win_pos >> 6)) ? win.bits
+                                                          : (uint64_t)__hip_atomic_load(ring + (int64_t)wd * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sp[(int64_t)(SL.TOTAL + 2 * wd) * n] = (double)(uint32_t)v;
+                sp[(int64_t)(SL.TOTAL + 2 * wd + 1) * n] = (double)(uint32_t)(v >> 32);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+bool rwm_row_serves(const RwmArgs &a, int target_kind)
+{
+    const bool full = a.d_Z || a.d_sigma_trace || a.d_accepted || a.d_log_acceptance || a.d_log_A || a.d_scaling_sd ||
+                      a.d_scaling_multiplier || a.d_rate_trace;
+    return !full && target_kind == MCMC_TARGET_GAUSSIAN_PREC && a.d >= 1 && a.d <= kMaxRowDimRwm;
+}
+
+template <int L>
+static int launch_rwm_row_l(const RwmArgs &a, const RwmParams &p, hipStream_t s)
+{
+    using Lay = RowLayout<L>;
+    const int d = a.d;
+    std::vector<double> blob(Lay::TOTAL, 0.0);
+    double min_var = p.cov_packed[0], prod0 = 1.0;
+    const double *Hm = p.tparams.data() + d; // column-major precision matrix
+    for (int k = 0; k < d; ++k) {
+        min_var = std::fmin(min_var, p.cov_packed[tri(k, k)]);
+        prod0 *= p.R0_packed[tri(k, k)];
+        blob[Lay::TMEAN + k] = p.tparams[k];
+        blob[Lay::INIT + k] = p.init[k];
+        for (int jj = 0; jj < d; ++jj) {
+            blob[Lay::HS + k * L + jj] = 0.5 * (Hm[(size_t)k * d + jj] + Hm[(size_t)jj * d + k]);
+            if (k <= jj) blob[Lay::R0 + k * L + jj] = p.R0_packed[tri(k, jj)];
+        }
+    }
+    blob[Lay::MINVAR] = min_var;
+    blob[Lay::PROD0] = prod0;
+    double *d_prm = nullptr;
+    MCMC_HIP_CHECK(hipMallocAsync((void **)&d_prm, blob.size() * sizeof(double), s));
+    hipError_t e = hipMemcpyAsync(d_prm, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s); // blob is a local: do not let the copy outlive it
+    if (e == hipSuccess) {
+        const size_t ldsb = (size_t)Lay::lds_doubles(d) * sizeof(double);
+        const unsigned grid = (unsigned)((a.n_chains + Lay::CPW - 1) / Lay::CPW);
+        if (a.d_state_in || a.d_state_out)
+            hipLaunchKernelGGL((rwm_row_kernel<L, true>), dim3(grid), dim3(256), ldsb, s, a, (const double *)d_prm);
+        else
+            hipLaunchKernelGGL((rwm_row_kernel<L, false>), dim3(grid), dim3(256), ldsb, s, a, (const double *)d_prm);
+        e = hipGetLastError();
+    }
+    hipError_t e2 = hipFreeAsync(d_prm, s);
+    if (e != hipSuccess) return set_error(MCMC_E_HIP, "rwm_row_kernel launch failed: %s", hipGetErrorString(e));
+    if (e2 != hipSuccess) return set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e2));
+    return MCMC_OK;
+}
+
+int launch_rwm_row(const RwmArgs &a, const RwmParams &p, hipStream_t s)
+{
+    if (!rwm_row_serves(a, p.target_kind))
+        return set_error(MCMC_E_UNSUPPORTED, "row kernel: Gaussian target, Philox streams, no per-iteration diagnostics, d <= %d", kMaxRowDimRwm);
+    if ((int)p.tparams.size() != a.d + a.d * a.d) return set_error(MCMC_E_BAD_ARG, "gaussian target needs d + d*d parameters");
+    return a.d <= 16 ? launch_rwm_row_l<16>(a, p, s) : launch_rwm_row_l<32>(a, p, s);
+}
+
+} // namespace mcmc

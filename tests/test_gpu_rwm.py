@@ -535,6 +535,91 @@ def test_paired_wave_kernel_targets_thinning_and_failure(cuda, oracle):
         mcmc_amd.adapt_rwm_batch(tgt, 4, np.zeros(d), np.eye(d), 10, diagnostics=True, kernel="pair")
 
 
+@pytest.mark.parametrize("d,n,ass,ashs,w,win", [(11, 700, 20, 150, 0.0, 0), (13, 600, 0, 120, 0.0, 0), (16, 700, 25, 160, 0.05, 0),
+                                                (24, 600, 0, 150, 0.0, 40), (32, 700, 0, 180, 0.0, 0), (17, 500, 15, 0, 0.0, 0),
+                                                (5, 500, 20, 60, 0.0, 0)])
+def test_row_kernel_matches_oracle_and_block_kernel(cuda, oracle, d, n, ass, ashs, w, win):
+    """One chain per row of 16 / 32 lanes (rwm_row.hip; what AUTO runs for 12 < d <= 32): a Philox run replayed through
+    the oracle with the streams mcmc_rwm_streams reports -- size phase, shape phase (in-register Cholesky every
+    iteration), the three rate modes -- and against the per-workgroup kernel on the same run."""
+    import mcmc_amd
+
+    nc = 37  # not a multiple of the 16 / 8 chains of a workgroup: the last one has shadow rows
+    rng = np.random.default_rng(2000 + d)
+    A = rng.standard_normal((d, d))
+    Sig = A @ A.T / d + np.eye(d)
+    H = np.linalg.inv(Sig)
+    H = 0.5 * (H + H.T)
+    m = 0.3 * rng.standard_normal(d)
+    tgt = mcmc_amd.Target.gaussian(m, H)
+    cov0 = (0.8 / d) * np.eye(d) + (0.1 / d) * np.ones((d, d))  # not diagonal: chol(covmat) has a full upper triangle
+    init = mcmc_amd.init_normal(9, nc, m, 1.0, chain_offset=500)
+    kw = dict(seed=21, chain_offset=500)
+    row = mcmc_amd.adapt_rwm_batch(tgt, nc, init, cov0, n, ass, w, win, ashs, kernel="row", **kw)
+    cuda.cuda.synchronize()
+    assert np.all(row["status"].cpu().numpy() == 0)
+    if d > 12:
+        auto = mcmc_amd.adapt_rwm_batch(tgt, nc, init, cov0, n, ass, w, win, ashs, **kw)
+        assert cuda.equal(auto["theta_trace"], row["theta_trace"])  # AUTO picks this kernel for 12 < d <= 32
+    other = mcmc_amd.adapt_rwm_batch(tgt, nc, init, cov0, n, ass, w, win, ashs, kernel="block" if d > 12 else "lane", **kw)
+    tr, to = row["theta_trace"].cpu().numpy(), other["theta_trace"].cpu().numpy()
+    assert _rel(tr, to) < BLOCK_RTOL, _rel(tr, to)
+    np.testing.assert_array_equal(row["acceptance_rate"].cpu().numpy(), other["acceptance_rate"].cpu().numpy())
+    np.testing.assert_array_equal(row["shape_iterations"].cpu().numpy(), other["shape_iterations"].cpu().numpy())
+    for key in ("final_theta", "final_mean", "final_cov"):
+        np.testing.assert_allclose(row[key].cpu().numpy(), other[key].cpu().numpy(), rtol=1e-9, atol=1e-12)
+    if ashs:
+        assert int(row["shape_iterations"].sum()) > 10 * nc
+    Z, U = mcmc_amd.rwm_streams(21, nc, n, d, chain_offset=500)
+    Z, U, x0 = Z.cpu().numpy(), U.cpu().numpy(), init.cpu().numpy()
+    for c in (0, 15, 16, 36):
+        ref = oracle.adaptMCMC(oracle.gaussian_target(m, H), x0[:, c], cov0, n, ass, w, win, ashs, Z[:, :, c], U[:, c])
+        assert _rel(tr[:, :, c], ref["theta_trace"]) < BLOCK_RTOL, (c, _rel(tr[:, :, c], ref["theta_trace"]))
+        assert row["acceptance_rate"].cpu().numpy()[c] == ref["acceptance_rate"]
+        np.testing.assert_allclose(row["final_cov"].cpu().numpy()[:, c].reshape(d, d, order="F"), ref["sigma_empirical"][:, :, -1],
+                                   rtol=1e-9, atol=1e-12)
+
+
+def test_row_kernel_sharding_thinning_resume_and_failure(cuda):
+    import mcmc_amd
+
+    for d in (16, 29):
+        Sig, H = _gauss(d, 0.7)
+        tgt = mcmc_amd.Target.gaussian(np.zeros(d), H)
+        cov0 = (1.0 / d) * np.eye(d)
+        ad = (10, 0.0, 0, 90)
+        kw = dict(seed=5, kernel="row")
+        whole = mcmc_amd.adapt_rwm_batch(tgt, 100, np.zeros(d), cov0, 400, *ad, **kw)
+        assert np.all(whole["status"].cpu().numpy() == 0) and int(whole["shape_iterations"].sum()) > 0
+        part = mcmc_amd.adapt_rwm_batch(tgt, 37, np.zeros(d), cov0, 400, *ad, chain_offset=63, **kw)
+        assert cuda.equal(whole["theta_trace"][:, :, 63:], part["theta_trace"])
+        thin = mcmc_amd.adapt_rwm_batch(tgt, 100, np.zeros(d), cov0, 400, *ad, thin=7, **kw)["theta_trace"]
+        assert thin.shape[0] == 57 and cuda.equal(thin, whole["theta_trace"][6::7][:57])
+        # a run split in three (inside the size phase, inside the shape phase) equals the uninterrupted one bit for bit
+        a = mcmc_amd.adapt_rwm_batch(tgt, 100, np.zeros(d), cov0, 55, *ad, checkpoint=True, **kw)
+        b = mcmc_amd.adapt_rwm_batch(tgt, 100, np.zeros(d), cov0, 245, *ad, checkpoint=True, resume=a["state"], **kw)
+        c3 = mcmc_amd.adapt_rwm_batch(tgt, 100, np.zeros(d), cov0, 100, *ad, resume=b["state"], **kw)
+        assert cuda.equal(cuda.cat([a["theta_trace"], b["theta_trace"], c3["theta_trace"]]), whole["theta_trace"])
+        for k in ("final_theta", "final_mean", "final_cov", "acceptance_rate", "shape_iterations"):
+            assert cuda.equal(c3[k], whole[k]), k
+        # under AUTO the checkpoint goes back to this kernel; the per-workgroup kernel refuses it on the device
+        c4 = mcmc_amd.adapt_rwm_batch(tgt, 100, np.zeros(d), cov0, 100, *ad, resume=b["state"], seed=5)
+        assert cuda.equal(c4["theta_trace"], c3["theta_trace"])
+        bad = mcmc_amd.adapt_rwm_batch(tgt, 100, np.zeros(d), cov0, 100, *ad, resume=b["state"], seed=5, kernel="block")
+        assert np.all((bad["status"].cpu().numpy() & 15) == mcmc_amd.MCMC_CHAIN_BAD_STATE)
+        # rank-deficient covmat_empirical: the failure iteration of the per-workgroup kernel (adaptMCMC_source.cpp:153)
+        fa = mcmc_amd.adapt_rwm_batch(tgt, 20, np.zeros(d), cov0, 60, 0, 0.0, 0, 1, seed=5, kernel="row")
+        fb = mcmc_amd.adapt_rwm_batch(tgt, 20, np.zeros(d), cov0, 60, 0, 0.0, 0, 1, seed=5, kernel="block")
+        sa, sb = fa["status"].cpu().numpy(), fb["status"].cpu().numpy()
+        assert np.all((sa & 15) == mcmc_amd.MCMC_CHAIN_CHOL_FAILED)
+        np.testing.assert_array_equal(sa, sb)
+        np.testing.assert_array_equal(np.isnan(fa["theta_trace"].cpu().numpy()), np.isnan(fb["theta_trace"].cpu().numpy()))
+    with pytest.raises(mcmc_amd.McmcError):
+        mcmc_amd.adapt_rwm_batch(tgt, 4, np.zeros(d), cov0, 10, diagnostics=True, kernel="row")  # refused, not rerouted
+    with pytest.raises(mcmc_amd.McmcError):
+        mcmc_amd.adapt_rwm_batch(mcmc_amd.Target.gaussian(np.zeros(40), np.eye(40)), 4, np.zeros(40), np.eye(40), 10, kernel="row")
+
+
 def test_run_chains_gives_the_list_of_chains_melt_trace_expects(cuda, oracle):
     """run_chains = the job of mclapply_RNG(X, adaptMCMC ...) (MCMCutilty.R:103-149) in one launch."""
     import mcmc_amd
