@@ -64,6 +64,104 @@ __device__ __forceinline__ void fmac_rb(double &acc, double x, double y)
 {
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(K));
 }
+// The same instruction in blocks, one asm statement each: the compiler closes every asm statement with an s_nop (it
+// cannot see what the last instruction inside was), which for single-instruction statements doubled the count.
+// acc += sum_k (x of lane 8 G + k of the row) * m[k], k = 0..7, in that order
+template <int G>
+__device__ __forceinline__ void fmac_dot8(double &acc, double x, const double *m);
+template <>
+__device__ __forceinline__ void fmac_dot8<0>(double &acc, double x, const double *m)
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %8 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(acc)
+        : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]));
+}
+template <>
+__device__ __forceinline__ void fmac_dot8<1>(double &acc, double x, const double *m)
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %3 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %4 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %5 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %6 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %7 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %8 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %9 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(acc)
+        : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]));
+}
+// a[k] += (x of lane k of the row) * y, k = 0..15
+__device__ __forceinline__ void fmac_rows16(double *a, double x, double y)
+{
+    asm("v_fmac_f64_dpp %0, %16, %17 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %16, %17 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %16, %17 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %16, %17 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %4, %16, %17 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %5, %16, %17 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %6, %16, %17 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %7, %16, %17 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %8, %16, %17 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %9, %16, %17 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %10, %16, %17 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %11, %16, %17 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %12, %16, %17 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %13, %16, %17 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %14, %16, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %15, %16, %17 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
+        : "v"(x), "v"(y));
+}
+// a[4 G + q] += (x of lane 4 G + q of the row) * y, q = 0..3
+template <int G>
+__device__ __forceinline__ void fmac_rows4(double *a, double x, double y);
+template <>
+__device__ __forceinline__ void fmac_rows4<0>(double *a, double x, double y)
+{
+    asm("v_fmac_f64_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %4, %5 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %4, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %4, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])
+        : "v"(x), "v"(y));
+}
+template <>
+__device__ __forceinline__ void fmac_rows4<1>(double *a, double x, double y)
+{
+    asm("v_fmac_f64_dpp %0, %4, %5 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %4, %5 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %4, %5 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %4, %5 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+        : "v"(x), "v"(y));
+}
+template <>
+__device__ __forceinline__ void fmac_rows4<2>(double *a, double x, double y)
+{
+    asm("v_fmac_f64_dpp %0, %4, %5 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %4, %5 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %4, %5 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %4, %5 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11])
+        : "v"(x), "v"(y));
+}
+template <>
+__device__ __forceinline__ void fmac_rows4<3>(double *a, double x, double y)
+{
+    asm("v_fmac_f64_dpp %0, %4, %5 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %4, %5 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %4, %5 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %4, %5 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
+        : "v"(x), "v"(y));
+}
 // x of lane K of this lane's 16-lane row
 template <int K>
 __device__ __forceinline__ double row_bcast(double x)
@@ -86,6 +184,20 @@ struct RowVec<16> {
     __device__ __forceinline__ void fmac(double &acc, double y) const { fmac_rb<K>(acc, lo, y); }
     template <int K>
     __device__ __forceinline__ double get() const { return row_bcast<K>(lo); }
+    // acc += sum_k v_k m[k] over the whole row, k ascending
+    template <int G>
+    __device__ __forceinline__ void dot8(double &acc, const double *m) const { fmac_dot8<G>(acc, lo, m); } // terms 8 G .. 8 G + 7
+    // a[k] += v_k y for every k
+    __device__ __forceinline__ void rows(double (&a)[16], double y) const { fmac_rows16(a, lo, y); }
+    // a[k] += v_k y for k >= 4 (P / 4): the rows of the group that holds P and all later ones
+    template <int P>
+    __device__ __forceinline__ void rows_from(double (&a)[16], double y) const
+    {
+        if constexpr (P / 4 <= 0) fmac_rows4<0>(a, lo, y);
+        if constexpr (P / 4 <= 1) fmac_rows4<1>(a, lo, y);
+        if constexpr (P / 4 <= 2) fmac_rows4<2>(a, lo, y);
+        if constexpr (P / 4 <= 3) fmac_rows4<3>(a, lo, y);
+    }
 };
 template <>
 struct RowVec<32> {
@@ -114,6 +226,31 @@ struct RowVec<32> {
             return row_bcast<K>(lo);
         else
             return row_bcast<K - 16>(hi);
+    }
+    template <int G>
+    __device__ __forceinline__ void dot8(double &acc, const double *m) const
+    {
+        if constexpr (G < 2)
+            fmac_dot8<G>(acc, lo, m);
+        else
+            fmac_dot8<G - 2>(acc, hi, m);
+    }
+    __device__ __forceinline__ void rows(double (&a)[32], double y) const
+    {
+        fmac_rows16(a, lo, y);
+        fmac_rows16(a + 16, hi, y);
+    }
+    template <int P>
+    __device__ __forceinline__ void rows_from(double (&a)[32], double y) const
+    {
+        if constexpr (P / 4 <= 0) fmac_rows4<0>(a, lo, y);
+        if constexpr (P / 4 <= 1) fmac_rows4<1>(a, lo, y);
+        if constexpr (P / 4 <= 2) fmac_rows4<2>(a, lo, y);
+        if constexpr (P / 4 <= 3) fmac_rows4<3>(a, lo, y);
+        if constexpr (P / 4 <= 4) fmac_rows4<0>(a + 16, hi, y);
+        if constexpr (P / 4 <= 5) fmac_rows4<1>(a + 16, hi, y);
+        if constexpr (P / 4 <= 6) fmac_rows4<2>(a + 16, hi, y);
+        if constexpr (P / 4 <= 7) fmac_rows4<3>(a + 16, hi, y);
     }
 };
 
@@ -194,9 +331,12 @@ __global__ __launch_bounds__(256, L == 16 ? 3 : 2) void rwm_row_kernel(const Rwm
         const double v = x - tm;
         const RowVec<L> vv(v);
         double g = 0.0;
-        row_unroll<0, L>([&](auto kc) {
-            constexpr int K = decltype(kc)::value;
-            vv.template fmac<K>(g, Hs[K * L]);
+        row_unroll<0, L / 8>([&](auto gc) { // eight terms per block: the row of H comes from LDS eight values at a time
+            constexpr int G = decltype(gc)::value;
+            double h[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) h[k] = Hs[(8 * G + k) * L];
+            vv.template dot8<G>(g, h);
         });
         return -0.5 * row_sum<L>(v * g);
     };
@@ -260,7 +400,9 @@ __global__ __launch_bounds__(256, L == 16 ? 3 : 2) void rwm_row_kernel(const Rwm
         // ---- adaptation of covmat_proposal (adaptMCMC_source.cpp:117-139), replicated ------------------
         bool rescale = false, refactor = false;
         if (ass != 0 && i >= ass && (ashs == 0 || mul_rn(rate, di) < (double)ashs)) {
-            const double scaling_multiplier = fm_exp(a.d_cool_pow[li] * (rate - 0.234));
+            // polynomial coefficients arrive by one scalar load per use (fastmath.h: fm_tab) instead of living in -- and
+            // spilling from -- scalar registers across the loop; same operations, same bits as fm_exp / fm_log
+            const double scaling_multiplier = fm_exp_t(a.d_cool_pow[li] * (rate - 0.234), fm_tab<16>(FT_EXP, i));
             scaling_sd = mul_rn(scaling_sd, scaling_multiplier);
             scaling_sd = (a.max_scaling_sd < scaling_sd) ? a.max_scaling_sd : scaling_sd;
             const double s2 = mul_rn(scaling_sd, scaling_sd);
@@ -300,15 +442,14 @@ __global__ __launch_bounds__(256, L == 16 ? 3 : 2) void rwm_row_kernel(const Rwm
                     prod *= rjj;
                     // finished row p of R: R_pj = a_pj / sqrt(a_pp) for j > p, the root itself at j = p, zero for j < p
                     const double rp = (j > P) ? Ac[P] * rinv : (j == P ? rjj : 0.0);
-                    Ac[P] = rp;
                     if constexpr (P + 1 < L) {
-                        const double nrp = -rp;
-                        const RowVec<L> rv(nrp);
-                        row_unroll<P + 1, L>([&](auto ic) { // a_ij -= R_pi R_pj; only the part i <= j is ever read
-                            constexpr int I = decltype(ic)::value;
-                            rv.template fmac<I>(Ac[I], rp);
-                        });
+                        // a_ij -= R_pi R_pj for the rows i > p (only the part i <= j is ever read), in groups of four
+                        // rows.  The group that holds p also meets rows i < p, where R_pi = 0 and nothing changes, and
+                        // row p itself, which is overwritten with the finished row right after.
+                        const RowVec<L> rv(-rp);
+                        rv.template rows_from<P + 1>(Ac, rp);
                     }
+                    Ac[P] = rp;
                 }
             });
 #pragma unroll
@@ -352,18 +493,23 @@ __global__ __launch_bounds__(256, L == 16 ? 3 : 2) void rwm_row_kernel(const Rwm
         }
 
         // ---- draws: this lane's normal, the chain's uniform (:149-152,174) ----------------------------------
-        double z0, z1, u0, u1;
-        philox_normal2(key, gchain, (uint32_t)i, TAG_RWM_NORMAL, (uint32_t)(j >> 1), z0, z1);
+        double z0, z1, u0, u1, logA;
+        {
+            PhiloxKey kk = key; // opaque copy: the ten round keys are formed by scalar adds here, not hoisted and spilled
+            asm volatile("" : "+s"(kk.k0), "+s"(kk.k1));
+            const ScalarCoef<16> tl = fm_tab<16>(FT_LOG, i), ts = fm_tab<16>(FT_SINCOS, i);
+            philox_normal2_t(kk, gchain, (uint32_t)i, TAG_RWM_NORMAL, (uint32_t)(j >> 1), z0, z1, tl, ts);
+            philox_uniform2(kk, gchain, (uint32_t)i, TAG_RWM_UNIFORM, 0u, u0, u1);
+            logA = fm_log_t(u0, tl); // A is in the open interval (0,1)
+        }
         const double Y = act ? ((j & 1) ? z1 : z0) : 0.0;
-        philox_uniform2(key, gchain, (uint32_t)i, TAG_RWM_UNIFORM, 0u, u0, u1);
-        const double logA = fm_log<true>(u0);
 
         // ---- proposal theta + s (Y R) (:153-154) and |Y|^2 for the Hastings term --------------------------------
         const RowVec<L> yv(Y);
         double yr = 0.0;
-        row_unroll<0, L>([&](auto kc) {
-            constexpr int K = decltype(kc)::value;
-            yv.template fmac<K>(yr, Rc[K]);
+        row_unroll<0, L / 8>([&](auto gc) {
+            constexpr int G = decltype(gc)::value;
+            yv.template dot8<G>(yr, Rc + 8 * G);
         });
         const double prop = theta + s_eff * yr;
         const double q = row_sum<L>(Y * Y);
@@ -375,7 +521,11 @@ __global__ __launch_bounds__(256, L == 16 ? 3 : 2) void rwm_row_kernel(const Rwm
             la = -__builtin_inf();
         } else {
             la = t_prop - t_cur;
-            const double p = fm_log<true>(rootTerm * fm_exp(-0.5 * q));
+            const double pe = rootTerm * fm_exp_t(-0.5 * q, fm_tab<16>(FT_EXP, li));
+            double p = fm_log_t(pe, fm_tab<16>(FT_LOG, li));
+            p = (pe == 0.0) ? -__builtin_inf() : p; // the special cases of fm_log<true>: the NaN-reject path needs them
+            p = (pe < 0.0 || pe != pe) ? __builtin_nan("") : p;
+            p = (pe == __builtin_inf()) ? pe : p;
             la = add_rn(la, p);
             la = add_rn(la, -p);
         }
@@ -421,12 +571,9 @@ __global__ __launch_bounds__(256, L == 16 ? 3 : 2) void rwm_row_kernel(const Rwm
             const double res = act ? theta - mean : 0.0;
             mean += res * inv_i;
             const RowVec<L> bv((sfac * inv_i) * res);
-            row_unroll<0, L>([&](auto kc) {
-                constexpr int K = decltype(kc)::value;
-                double v = Cc[K] * sfac;
-                bv.template fmac<K>(v, res);
-                Cc[K] = v;
-            });
+#pragma unroll
+            for (int k = 0; k < L; ++k) Cc[k] *= sfac;
+            bv.rows(Cc, res);
         }
     }
 
