@@ -28,6 +28,12 @@ __global__ __launch_bounds__(256) void k(double *out, double seed, long long *cy
     const double b = 1.0000001, c = 1e-9;
     double x = 1e-7 * threadIdx.x, y = 1e-3;
     d4 m0 = {0, 0, 0, 0}, m1 = m0, m2 = m0, m3 = m0;
+    double T[28];
+    d4 M[7];
+#pragma unroll
+    for (int q = 0; q < 28; ++q) T[q] = seed * q;
+#pragma unroll
+    for (int t = 0; t < 7; ++t) M[t] = m0;
     long long t0 = __builtin_amdgcn_s_memtime();
 #pragma unroll 1
     for (int i = 0; i < ITERS; ++i) {
@@ -62,10 +68,45 @@ __global__ __launch_bounds__(256) void k(double *out, double seed, long long *cy
                 auto hi = __builtin_amdgcn_permlane16_swap((uint32_t)(u >> 32), (uint32_t)(u >> 32), false, false);
                 a0 = __longlong_as_double((long long)(((uint64_t)hi[0] << 32) | lo[0])) + __longlong_as_double((long long)(((uint64_t)hi[1] << 32) | lo[1]));
             }
+        } else if (MODE == 7) {
+            // rank-16 trailing update of the d = 100 Cholesky as rwm_block.hip does it: per pivot every thread updates its
+            // 28 tile elements, a_ik -= (a_ji / a_jj) a_jk -- 28 FMAs with 7 + 7 operands (here from registers; the kernel
+            // reads them from LDS and scales one side), 16 pivots = one 16-row panel
+#pragma unroll
+            for (int piv = 0; piv < 16; ++piv) {
+                const double r0 = a0 * (piv + 1), r1 = a1 + piv, r2 = a2 - piv, r3 = a3 * 0.5, r4 = a4, r5 = a5, r6 = a6;
+                int q = 0;
+#pragma unroll
+                for (int bb = 0; bb < 7; ++bb) {
+                    const double rk = (bb == 0 ? r0 : bb == 1 ? r1 : bb == 2 ? r2 : bb == 3 ? r3 : bb == 4 ? r4 : bb == 5 ? r5 : r6);
+#pragma unroll
+                    for (int aa = 0; aa <= bb; ++aa, ++q) {
+                        const double ri = (aa == 0 ? r6 : aa == 1 ? r5 : aa == 2 ? r4 : aa == 3 ? r3 : aa == 4 ? r2 : aa == 5 ? r1 : r0);
+                        T[q] = fma(-ri, rk, T[q]);
+                    }
+                }
+            }
+        } else if (MODE == 8) {
+            // the same update with the matrix cores: a wave owns 7 of the 28 tiles (16 x 16 accumulators, 8 VGPRs each) and
+            // applies the 16-row panel as four 16x16x4 steps per tile: 28 v_mfma_f64_16x16x4_f64 per wave and panel
+#pragma unroll
+            for (int t = 0; t < 7; ++t) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) M[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x + ks, y - t, M[t], 0, 0, 0);
+            }
         }
     }
     long long t1 = __builtin_amdgcn_s_memtime();
-    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + m0[0] + m1[1] + m2[2] + m3[3];
+    double extra = 0.0;
+    if (MODE == 7) {
+#pragma unroll
+        for (int q = 0; q < 28; ++q) extra += T[q];
+    }
+    if (MODE == 8) {
+#pragma unroll
+        for (int t = 0; t < 7; ++t) extra += M[t][0] + M[t][3];
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = extra + a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + m0[0] + m1[1] + m2[2] + m3[3];
     if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
 }
 
@@ -137,6 +178,8 @@ int main()
         run<4>("mfma_f64_16x16x4 dependent", 4, w, d_out, d_cyc);
         run<5>("1 mfma_f64 + 8 fma_f64 (per group)", 1, w, d_out, d_cyc);
         run<6>("permlane16_swap pair + add x4", 4, w, d_out, d_cyc);
+        run<7>("16-row panel update, VALU (448 fma)", 1, w, d_out, d_cyc);
+        run<8>("16-row panel update, MFMA (28 mfma)", 1, w, d_out, d_cyc);
     }
     return 0;
 }
