@@ -148,20 +148,25 @@ struct DotPos {
     static constexpr int value = Q;
 };
 
-template <bool TAIL_SAFE, bool MOMENTS>
-__global__ __launch_bounds__(768) void gibbs_reg_kernel(const GibbsArgs a, const double *__restrict__ rows, int W, int G, int NDW)
+// dot waves per group NDW (1: d <= 64, 2: d <= 128, 4: d <= 256) and with it the group count are compile-time constants
+__host__ __device__ constexpr int reg_groups(int ndw) { return ndw == 1 ? 6 : (ndw == 2 ? 4 : 2); } // 12 / 12 / 10 waves, three per SIMD at most
+
+template <bool TAIL_SAFE, bool MOMENTS, int NDW>
+__global__ __launch_bounds__(768) void gibbs_reg_kernel(const GibbsArgs a, const double *__restrict__ rows, int W)
 {
+    constexpr int G = reg_groups(NDW);
     extern __shared__ double lds[]; // [3][64 NDW + kRegTail] row ring, [G][2][NDW + 1][64] slots (partial sums, u), [G][2][64] new x
-    const int NS = NDW + 1;
-    const int tid = threadIdx.x, nthreads = blockDim.x;
+    constexpr int NS = NDW + 1;
+    constexpr int nthreads = G * (1 + NDW) * 64;
+    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool dotter = wave >= G;
     const int group = dotter ? (wave - G) % G : wave;
     const int part = dotter ? (wave - G) / G : 0;
     const int d = a.d;
-    const int TW = NDW * kRegOwn;  // dot-visible entries of a ring row
-    const int W2 = TW + kRegTail;  // ring row stride
+    constexpr int TW = NDW * kRegOwn;  // dot-visible entries of a ring row
+    constexpr int W2 = TW + kRegTail;  // ring row stride
     const int64_t c = ((int64_t)blockIdx.x * G + group) * 64 + lane;
     const int64_t n = a.n_chains;
     const bool live = c < n;
@@ -457,18 +462,22 @@ static int launch_gibbs_on_block(const GibbsArgs &a, bool tail_safe, const doubl
         // state in the dot waves' registers, 64 coordinates each; group and wave counts are functions of d only, so
         // that results do not depend on how chains are split over launches
         const int NDW = d <= kRegOwn ? 1 : (d <= 2 * kRegOwn ? 2 : 4); // dot waves per group
-        const int G = NDW == 1 ? 6 : (NDW == 2 ? 4 : 2);               // groups per workgroup: 12 / 12 / 10 waves, three per SIMD at most
+        const int G = reg_groups(NDW);                                 // groups per workgroup
         const int threads = G * (1 + NDW) * 64;
         if ((W + threads - 1) / threads > kWideMaxPrefetch) return set_error(MCMC_E_UNSUPPORTED, "gibbs: d=%d too wide", d);
         const size_t ldsr = ((size_t)3 * (NDW * kRegOwn + kRegTail) + (size_t)G * (2 * (NDW + 1) * 64 + 128)) * sizeof(double);
         const int64_t gridr = (a.n_chains + 64 * G - 1) / (64 * G);
         auto gor = [&](auto kern) -> int {
-            hipLaunchKernelGGL(kern, dim3((unsigned)gridr), dim3(threads), ldsr, s, a, d_blk, W, G, NDW);
+            hipLaunchKernelGGL(kern, dim3((unsigned)gridr), dim3(threads), ldsr, s, a, d_blk, W);
             hipError_t el = hipGetLastError();
             return el == hipSuccess ? MCMC_OK : set_error(MCMC_E_HIP, "gibbs_reg_kernel launch failed: %s", hipGetErrorString(el));
         };
-        if (tail_safe) return moments ? gor(gibbs_reg_kernel<true, true>) : gor(gibbs_reg_kernel<true, false>);
-        return moments ? gor(gibbs_reg_kernel<false, true>) : gor(gibbs_reg_kernel<false, false>);
+        auto pick = [&](auto ndw) -> int {
+            constexpr int N = decltype(ndw)::value;
+            if (tail_safe) return moments ? gor(gibbs_reg_kernel<true, true, N>) : gor(gibbs_reg_kernel<true, false, N>);
+            return moments ? gor(gibbs_reg_kernel<false, true, N>) : gor(gibbs_reg_kernel<false, false, N>);
+        };
+        return NDW == 1 ? pick(DotPos<1>{}) : (NDW == 2 ? pick(DotPos<2>{}) : pick(DotPos<4>{}));
     }
     const size_t lds = (size_t)d * 64 * sizeof(double);
     const int64_t grid = (a.n_chains + 63) / 64;
