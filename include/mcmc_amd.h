@@ -378,6 +378,48 @@ int mcmc_pooled_cov_partial(const double *d_mean, const double *d_cov, int32_t d
 int mcmc_chain_ess(const double *d_trace, int32_t n_kept, int32_t burn_kept, int32_t d,
                    int64_t n_chains, int32_t max_lag, double *d_ess, void *stream);
 
+/* =====================================================================================
+ * Outside the two samplers: the multivariate normal density helpers of
+ * deprecated/truncGaussian.cpp and the toy walkers of randomWalkers.cpp.
+ * ===================================================================================== */
+/* replaces: double mvrGaussian_pdf(arma::vec x, arma::vec mu, arma::mat sigma, bool do_log = true)
+ * (deprecated/truncGaussian.cpp:11-33): rootTerm * exp(-0.5 (x-mu)^T sigma^-1 (x-mu)), logged afterwards if do_log.
+ * Batch form: d_x is [d][n] (n points), d_out [n].  Waits for the launch (its parameter block is a local). */
+int mcmc_mvrGaussian_pdf_batch(int32_t d, int64_t n, const double *d_x, const double *h_mu, const double *h_sigma,
+                               int32_t do_log, double *d_out, void *stream);
+int mcmc_mvrGaussian_pdf(int32_t d, const double *h_x, const double *h_mu, const double *h_sigma, int32_t do_log, double *out);
+/* replaces: double tmvrGaussian_pdf(NumericVector x, NumericVector mu, NumericMatrix sigma, NumericVector lower,
+ * NumericVector upper) (deprecated/truncGaussian.cpp:38-78): 0 outside [lower, upper] (:45-63), else
+ * mvrGaussian_pdf(x, mu, sigma) / cdf -- with the reference's own default do_log = true at :73, i.e. the LOG
+ * density over cdf.  `cdf` is what the reference gets from mvtnorm::pmvnorm(lower, upper, mu, sigma) (:68-75), a
+ * third-party randomized integral: pass that value, or mcmc_pmvnorm's. */
+int mcmc_tmvrGaussian_pdf_batch(int32_t d, int64_t n, const double *d_x, const double *h_mu, const double *h_sigma,
+                                const double *h_lower, const double *h_upper, double cdf, double *d_out, void *stream);
+int mcmc_tmvrGaussian_pdf(int32_t d, const double *h_x, const double *h_mu, const double *h_sigma, const double *h_lower,
+                          const double *h_upper, double cdf, double *out);
+/* P(lower <= X <= upper), X ~ N(mu, sigma), d <= 32, by Genz' separation-of-variables estimator over n_points Philox
+ * points on the device; *std_err (may be NULL) is the Monte Carlo standard error.  Stands in for the
+ * mvtnorm::pmvnorm call of deprecated/truncGaussian.cpp:74 -- same estimand, other random numbers: PARITY UNPINNED. */
+int mcmc_pmvnorm(int32_t d, const double *h_lower, const double *h_upper, const double *h_mu, const double *h_sigma,
+                 int64_t n_points, uint64_t seed, double *prob, double *std_err);
+/* replaces: NumericMatrix random_walk2d(int n) / random_walk3d(int n) (randomWalkers.cpp:9-37, :40-74): row 0 is the
+ * origin, step i moves +-1 along axis (r-1)/2 with r = 1 + floor(runif * 2 dim).  h_out is n x dim column-major;
+ * h_U optional (the n-1 runif draws in order), NULL = Philox(seed).  Batch form: d_U [n-1][n_walkers] or NULL,
+ * d_out [n][dim][n_walkers], walker w has global id walker_offset + w. */
+int mcmc_random_walk2d(int32_t n, const double *h_U, uint64_t seed, double *h_out);
+int mcmc_random_walk3d(int32_t n, const double *h_U, uint64_t seed, double *h_out);
+int mcmc_random_walk_batch(int32_t dim, int32_t n, int64_t n_walkers, int64_t walker_offset, const double *d_U, uint64_t seed,
+                           double *d_out, void *stream);
+/* replaces: NumericVector random_walkGraph(NumericMatrix graph, int init_pos, int n) (randomWalkers.cpp:80-100): from
+ * node p the next node is RcppArmadillo::sample(0..n_nodes-1, 1, false, graph(p, _)) -- probabilities normalised, sorted
+ * in descending order, first position whose running sum reaches unif_rand() (rows with equal weights: the tie order
+ * of Armadillo's sort is unspecified, here index order).  h_graph is n_nodes x n_nodes column-major, nodes 0-based;
+ * h_U optional (n-1 draws).  Batch form: d_U [n-1][n_walkers] or NULL, d_out [n][n_walkers]; waits for the launch. */
+int mcmc_random_walkGraph(int32_t n_nodes, const double *h_graph, int32_t init_pos, int32_t n, const double *h_U, uint64_t seed,
+                          double *h_out);
+int mcmc_random_walkGraph_batch(int32_t n_nodes, const double *h_graph, int32_t init_pos, int32_t n, int64_t n_walkers,
+                                int64_t walker_offset, const double *d_U, uint64_t seed, double *d_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

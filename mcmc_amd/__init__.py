@@ -10,5 +10,7 @@ from ._lib import (  # noqa: F401
 from .api import (  # noqa: F401
     RwmState, Target, adaptMCMC, adapt_rwm_batch, gibbs_streams, init_normal, negSubCol, negSubRow, rtmvnorm_gibbs,
     rtnorm_batch, rtnorm_gibbs, rwMCMC, rwm_streams, sub1, sub2, target_eval_batch, tmvn_gibbs_batch, tmvn_precompute,
+    mvrGaussian_pdf, tmvrGaussian_pdf, pmvnorm, random_walk2d, random_walk3d, random_walk_batch, random_walkGraph,
+    random_walkGraph_batch,
 )
 from .chains import chain_list, melt_trace, run_chains  # noqa: F401,E402

@@ -122,6 +122,16 @@ SIGNATURES = {
     "mcmc_rhat_partial": (C.c_int, [vp, vp, C.c_int32, C.c_int64, vp, vp]),
     "mcmc_pooled_cov_partial": (C.c_int, [vp, vp, C.c_int32, C.c_int64, vp, vp]),
     "mcmc_chain_ess": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, vp, vp]),
+    "mcmc_mvrGaussian_pdf_batch": (C.c_int, [C.c_int32, C.c_int64, vp, dp, dp, C.c_int32, vp, vp]),
+    "mcmc_mvrGaussian_pdf": (C.c_int, [C.c_int32, dp, dp, dp, C.c_int32, dp]),
+    "mcmc_tmvrGaussian_pdf_batch": (C.c_int, [C.c_int32, C.c_int64, vp, dp, dp, dp, dp, C.c_double, vp, vp]),
+    "mcmc_tmvrGaussian_pdf": (C.c_int, [C.c_int32, dp, dp, dp, dp, dp, C.c_double, dp]),
+    "mcmc_pmvnorm": (C.c_int, [C.c_int32, dp, dp, dp, dp, C.c_int64, C.c_uint64, dp, dp]),
+    "mcmc_random_walk2d": (C.c_int, [C.c_int32, dp, C.c_uint64, dp]),
+    "mcmc_random_walk3d": (C.c_int, [C.c_int32, dp, C.c_uint64, dp]),
+    "mcmc_random_walk_batch": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int64, vp, C.c_uint64, vp, vp]),
+    "mcmc_random_walkGraph": (C.c_int, [C.c_int32, dp, C.c_int32, C.c_int32, dp, C.c_uint64, dp]),
+    "mcmc_random_walkGraph_batch": (C.c_int, [C.c_int32, dp, C.c_int32, C.c_int32, C.c_int64, C.c_int64, vp, C.c_uint64, vp, vp]),
 }
 
 

@@ -523,3 +523,111 @@ def rtnorm_batch(n, mu, sigma, a, b, *, F=None, seed=0, offset=0, tail_safe=Fals
     check(lib.mcmc_rtnorm_batch(int(n), float(mu), float(sigma), float(a), float(b), _dev_ptr(F), int(seed),
                                 int(offset), 1 if tail_safe else 0, _dev_ptr(out), _stream_ptr()))
     return out
+
+
+# --------------------------------------------------------------------------- outside the samplers
+def mvrGaussian_pdf(x, mu, sigma, do_log=True):
+    """mvrGaussian_pdf (deprecated/truncGaussian.cpp:11-33).  x: a length-d vector -> a float, or a [d, n] CUDA
+    tensor of n points -> an [n] CUDA tensor."""
+    mu = _vec(mu)
+    d = mu.size
+    sg = _colmajor(sigma, d)
+    if hasattr(x, "is_cuda"):
+        torch = _torch()
+        out = torch.empty((x.shape[1],), dtype=torch.float64, device=x.device)
+        check(lib.mcmc_mvrGaussian_pdf_batch(d, int(x.shape[1]), _dev_ptr(x, torch.float64), _p(mu), _p(sg), 1 if do_log else 0,
+                                             _dev_ptr(out), _stream_ptr()))
+        return out
+    xv = _vec(x)
+    out = C.c_double(0.0)
+    check(lib.mcmc_mvrGaussian_pdf(d, _p(xv), _p(mu), _p(sg), 1 if do_log else 0, C.byref(out)))
+    return out.value
+
+
+def tmvrGaussian_pdf(x, mu, sigma, lower, upper, cdf=None, *, n_points=1 << 20, seed=0):
+    """tmvrGaussian_pdf (deprecated/truncGaussian.cpp:38-78).  cdf = the pmvnorm(lower, upper, mu, sigma) value the
+    reference takes from CRAN mvtnorm (:74); None computes it with pmvnorm() below."""
+    mu, lower, upper = _vec(mu), _vec(lower), _vec(upper)
+    d = mu.size
+    sg = _colmajor(sigma, d)
+    if cdf is None:
+        cdf = pmvnorm(lower, upper, mu, sigma, n_points=n_points, seed=seed)[0]
+    if hasattr(x, "is_cuda"):
+        torch = _torch()
+        out = torch.empty((x.shape[1],), dtype=torch.float64, device=x.device)
+        check(lib.mcmc_tmvrGaussian_pdf_batch(d, int(x.shape[1]), _dev_ptr(x, torch.float64), _p(mu), _p(sg), _p(lower), _p(upper),
+                                              float(cdf), _dev_ptr(out), _stream_ptr()))
+        return out
+    xv = _vec(x)
+    out = C.c_double(0.0)
+    check(lib.mcmc_tmvrGaussian_pdf(d, _p(xv), _p(mu), _p(sg), _p(lower), _p(upper), float(cdf), C.byref(out)))
+    return out.value
+
+
+def pmvnorm(lower, upper, mu, sigma, *, n_points=1 << 20, seed=0):
+    """P(lower <= X <= upper) for X ~ N(mu, sigma) (Genz separation of variables on the device): (estimate, std error)."""
+    mu, lower, upper = _vec(mu), _vec(lower), _vec(upper)
+    sg = _colmajor(sigma, mu.size)
+    prob, err = C.c_double(0.0), C.c_double(0.0)
+    check(lib.mcmc_pmvnorm(mu.size, _p(lower), _p(upper), _p(mu), _p(sg), int(n_points), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                           C.byref(prob), C.byref(err)))
+    return prob.value, err.value
+
+
+def _walk(fn, dim, n, U, seed):
+    n = int(n)
+    uu = None
+    if U is not None:
+        uu = _vec(U)
+        if uu.size < n - 1:
+            raise ValueError("U must hold n-1 uniforms")
+    out = np.empty(n * dim)
+    check(fn(n, _p(uu), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(out)))
+    return out.reshape(n, dim, order="F")
+
+
+def random_walk2d(n, *, U=None, seed=0):
+    """random_walk2d (randomWalkers.cpp:9-37): n x 2 matrix."""
+    return _walk(lib.mcmc_random_walk2d, 2, n, U, seed)
+
+
+def random_walk3d(n, *, U=None, seed=0):
+    """random_walk3d (randomWalkers.cpp:40-74): n x 3 matrix."""
+    return _walk(lib.mcmc_random_walk3d, 3, n, U, seed)
+
+
+def random_walk_batch(dim, n, n_walkers, *, U=None, seed=0, walker_offset=0, device="cuda"):
+    """Many lattice walkers in one launch: [n, dim, n_walkers] CUDA tensor; U [n-1, n_walkers] injects the uniforms."""
+    torch = _torch()
+    out = torch.empty((int(n), int(dim), int(n_walkers)), dtype=torch.float64, device=device)
+    check(lib.mcmc_random_walk_batch(int(dim), int(n), int(n_walkers), int(walker_offset), _dev_ptr(U), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                     _dev_ptr(out), _stream_ptr()))
+    return out
+
+
+def random_walkGraph(graph, init_pos, n, *, U=None, seed=0):
+    """random_walkGraph (randomWalkers.cpp:80-100): the n visited nodes (0-based)."""
+    graph = np.asarray(graph, dtype=np.float64)
+    nn = graph.shape[0]
+    g = _colmajor(graph, nn)
+    n = int(n)
+    uu = None
+    if U is not None:
+        uu = _vec(U)
+        if uu.size < n - 1:
+            raise ValueError("U must hold n-1 uniforms")
+    out = np.empty(n)
+    check(lib.mcmc_random_walkGraph(nn, _p(g), int(init_pos), n, _p(uu), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(out)))
+    return out
+
+
+def random_walkGraph_batch(graph, init_pos, n, n_walkers, *, U=None, seed=0, walker_offset=0, device="cuda"):
+    """Many graph walkers in one launch: [n, n_walkers] CUDA tensor; U [n-1, n_walkers] injects the uniforms."""
+    torch = _torch()
+    graph = np.asarray(graph, dtype=np.float64)
+    nn = graph.shape[0]
+    g = _colmajor(graph, nn)
+    out = torch.empty((int(n), int(n_walkers)), dtype=torch.float64, device=device)
+    check(lib.mcmc_random_walkGraph_batch(nn, _p(g), int(init_pos), int(n), int(n_walkers), int(walker_offset), _dev_ptr(U),
+                                          int(seed) & 0xFFFFFFFFFFFFFFFF, _dev_ptr(out), _stream_ptr()))
+    return out

@@ -112,7 +112,7 @@ struct DppCtrl {
 
 // USER: the target is mcmc_user_target_part (run-time compiled module); its parameters take the place of Hq
 template <int NT, bool FULL, bool USER>
-__global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : 3) void rwm_block_kernel(const RwmArgs a, const double *__restrict__ prm)
+__global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) void rwm_block_kernel(const RwmArgs a, const double *__restrict__ prm)
 {
     extern __shared__ double lds[];
     const int d = a.d;

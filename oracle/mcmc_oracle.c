@@ -858,3 +858,111 @@ int orc_adapt_mcmc_seeded(int target_id, void *ctx, int d, const double *init_th
     free(U);
     return st;
 }
+
+/* ------------------------------------------------------------------------- */
+/* truncated-MVN density and the toy walkers    */
+/* ------------------------------------------------------------------------- */
+
+/* mvrGaussian_pdf, deprecated/truncGaussian.cpp:11-33: the un-logged density first, then log if do_log */
+double orc_mvrGaussian_pdf(int d, const double *x, const double *mu, const double *sigma, int do_log)
+{
+    double lg = orc_mvrnorm_pdf(d, x, mu, sigma); /* log(rootTerm * expTerm): the same statements as :19-26 */
+    if (do_log) return lg;
+    {
+        /* out = rootTerm * expTerm itself (:28,32): redo the product rather than exp(log(.)) */
+        double twoPi = 2 * M_PI;
+        double rootTerm = 1 / sqrt(pow(twoPi, d) * orc_det(d, sigma));
+        double *Sinv = (double *)malloc(sizeof(double) * d * d);
+        double *v = (double *)malloc(sizeof(double) * d);
+        double q = 0.0, out;
+        int i, j;
+        if (orc_inv(d, sigma, Sinv) != ORC_OK)
+            for (i = 0; i < d * d; ++i) Sinv[i] = NAN;
+        for (i = 0; i < d; ++i) v[i] = x[i] - mu[i];
+        for (j = 0; j < d; ++j) {
+            double s = 0.0;
+            for (i = 0; i < d; ++i) s += v[i] * AT(Sinv, i, j, d);
+            q += (-0.5 * s) * v[j];
+        }
+        out = rootTerm * exp(q);
+        free(Sinv);
+        free(v);
+        (void)lg;
+        return out;
+    }
+}
+
+/* tmvrGaussian_pdf, deprecated/truncGaussian.cpp:38-78.  `cdf` is the value the reference obtains from
+ * mvtnorm::pmvnorm(lower, upper, mu, sigma) (:74-75; a third-party randomized integral, not restated here).
+ * Quirk kept: mvrGaussian_pdf is called with its default do_log = true (:73), so the LOG density is divided by cdf. */
+double orc_tmvrGaussian_pdf(int d, const double *x, const double *mu, const double *sigma, const double *lower,
+                            const double *upper, double cdf)
+{
+    int i;
+    for (i = 0; i < d; ++i)
+        if (!((x[i] >= lower[i]) && (x[i] <= upper[i]))) return 0.0; /* outside the support (:45-63) */
+    return orc_mvrGaussian_pdf(d, x, mu, sigma, 1) / cdf;
+}
+
+/* random_walk2d / random_walk3d, randomWalkers.cpp:9-74: out is n x dim column-major, row 0 the origin;
+ * step i uses U[i-1] = R::runif(0,1): r_num = 1 + floor(U * 2 dim); odd r_num: +1, even: -1 on axis (r_num-1)/2 */
+void orc_random_walk(int dim, int n, const double *U, double *out)
+{
+    int i, k;
+    for (k = 0; k < dim; ++k) out[(size_t)k * n] = 0.0;
+    for (i = 1; i < n; ++i) {
+        double r_num = 1 + floor(U[i - 1] * (2 * dim));
+        for (k = 0; k < dim; ++k) out[(size_t)k * n + i] = out[(size_t)k * n + i - 1];
+        for (k = 0; k < dim; ++k) {
+            if (r_num == 2 * k + 1) out[(size_t)k * n + i] = out[(size_t)k * n + i - 1] + 1;
+            if (r_num == 2 * k + 2) out[(size_t)k * n + i] = out[(size_t)k * n + i - 1] - 1;
+        }
+    }
+}
+
+/* random_walkGraph, randomWalkers.cpp:80-100: out(i) = RcppArmadillo::sample(0..nn-1, 1, false, graph(out(i-1), _)).
+ * RcppArmadillo's sample.h is third-party and not under /root/reference; restated from its published algorithm
+ * (FixProb + ProbSampleNoReplace, the C++ transcription of R's do_sample): the probabilities are normalised,
+ * sorted in DESCENDING order carrying their indices, and the first position whose running sum reaches
+ * rT = unif_rand() is taken (the last position if none does).  Ties in the sort keep index order here; Armadillo's
+ * sort_index does not promise that -- PARITY UNPINNED for rows with equal probabilities. */
+int orc_random_walkGraph(int nn, const double *graph, int init_pos, int n, const double *U, double *out)
+{
+    double *p = (double *)malloc(sizeof(double) * nn);
+    int *perm = (int *)malloc(sizeof(int) * nn);
+    int i, j, k, status = ORC_OK;
+    if (init_pos < 0 || init_pos >= nn) status = ORC_BAD_ARG;
+    if (n > 0) out[0] = init_pos;
+    for (i = 1; i < n && status == ORC_OK; ++i) {
+        int pos = (int)out[i - 1];
+        double sum = 0.0, mass = 0.0, rT;
+        for (k = 0; k < nn; ++k) {
+            p[k] = AT(graph, pos, k, nn); /* graph(pos_begin, _) */
+            perm[k] = k;
+            if (!(p[k] >= 0.0) || !isfinite(p[k])) status = ORC_BAD_ARG;
+            sum += p[k];
+        }
+        if (!(sum > 0.0)) status = ORC_BAD_ARG;
+        if (status != ORC_OK) break;
+        for (k = 0; k < nn; ++k) p[k] = p[k] / sum;
+        for (k = 1; k < nn; ++k) { /* stable insertion sort, descending */
+            double pk = p[k];
+            int ik = perm[k];
+            for (j = k - 1; j >= 0 && p[j] < pk; --j) {
+                p[j + 1] = p[j];
+                perm[j + 1] = perm[j];
+            }
+            p[j + 1] = pk;
+            perm[j + 1] = ik;
+        }
+        rT = U[i - 1];
+        for (j = 0; j < nn - 1; ++j) {
+            mass += p[j];
+            if (rT <= mass) break;
+        }
+        out[i] = perm[j];
+    }
+    free(p);
+    free(perm);
+    return status;
+}

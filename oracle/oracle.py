@@ -379,3 +379,37 @@ def rtmvnorm_gibbs(n, mu, sigma, lower, upper, init_state, U):
     if st != ORC_OK:
         raise RuntimeError(f"oracle rtmvnorm_gibbs failed: status {st}")
     return trace.reshape(n, d, order="F")
+
+
+# ---- SURVEY.md section 8(f) row 4 -------------------------------------------------------------
+def mvrGaussian_pdf(x, mu, sigma, do_log=True):
+    """deprecated/truncGaussian.cpp:11-33"""
+    x, mu = _f64(x), _f64(mu)
+    lib().orc_mvrGaussian_pdf.restype = C.c_double
+    return lib().orc_mvrGaussian_pdf(x.size, _p(x), _p(mu), _p(_colmajor(sigma)), 1 if do_log else 0)
+
+
+def tmvrGaussian_pdf(x, mu, sigma, lower, upper, cdf):
+    """deprecated/truncGaussian.cpp:38-78 with cdf = the pmvnorm(lower, upper, mu, sigma) value of :74-75"""
+    x, mu, lower, upper = _f64(x), _f64(mu), _f64(lower), _f64(upper)
+    lib().orc_tmvrGaussian_pdf.restype = C.c_double
+    return lib().orc_tmvrGaussian_pdf(x.size, _p(x), _p(mu), _p(_colmajor(sigma)), _p(lower), _p(upper), C.c_double(cdf))
+
+
+def random_walk(dim, n, U):
+    """random_walk2d / random_walk3d (randomWalkers.cpp:9-74): n x dim, U = the n-1 runif draws"""
+    U = _f64(U)
+    out = np.zeros(n * dim)
+    lib().orc_random_walk(int(dim), int(n), _p(U), _p(out))
+    return out.reshape(n, dim, order="F")
+
+
+def random_walkGraph(graph, init_pos, n, U):
+    """random_walkGraph (randomWalkers.cpp:80-100), 0-based nodes, U = the n-1 unif_rand draws of sample()"""
+    graph = np.asarray(graph, dtype=np.float64)
+    U = _f64(U)
+    out = np.zeros(n)
+    st = lib().orc_random_walkGraph(graph.shape[0], _p(_colmajor(graph)), int(init_pos), int(n), _p(U), _p(out))
+    if st != ORC_OK:
+        raise RuntimeError(f"oracle random_walkGraph failed: status {st}")
+    return out

@@ -266,3 +266,45 @@ def test_committed_golden_vectors_are_reproduced_bit_for_bit(oracle):
                       diagnostics=True)
     assert np.isnan(r["diag"]["log_acceptance"][10]) and r["diag"]["log_acceptance"][50] == -np.inf
     np.testing.assert_array_equal(r["theta_trace"], g["theta_trace"])
+
+
+def test_density_helpers_and_walkers_restatement(oracle):
+    """mvrGaussian_pdf / tmvrGaussian_pdf (deprecated/truncGaussian.cpp:11-78) against scipy,
+    the lattice walkers (randomWalkers.cpp:9-74) against a numpy cumulative sum, the graph walker (:80-100) against a
+    direct transcription of R's ProbSampleNoReplace for one draw."""
+    from scipy.stats import multivariate_normal as mvn
+
+    rng = np.random.default_rng(0)
+    d = 4
+    A = rng.standard_normal((d, d))
+    S, mu, x = A @ A.T + np.eye(d), rng.standard_normal(d), rng.standard_normal(d)
+    np.testing.assert_allclose(oracle.mvrGaussian_pdf(x, mu, S), mvn(mu, S).logpdf(x), rtol=1e-13)
+    np.testing.assert_allclose(oracle.mvrGaussian_pdf(x, mu, S, do_log=False), mvn(mu, S).pdf(x), rtol=1e-13)
+    lo, hi = x - 1, x + 1
+    assert oracle.tmvrGaussian_pdf(x, mu, S, lo, hi, 0.5) == oracle.mvrGaussian_pdf(x, mu, S) / 0.5  # LOG density over cdf (:73-76)
+    assert oracle.tmvrGaussian_pdf(x, mu, S, x + 0.1, hi, 0.5) == 0.0                                 # outside the support (:61-63)
+    for dim in (2, 3):
+        U = rng.random(99)
+        w = oracle.random_walk(dim, 100, U)
+        r = 1 + np.floor(U * 2 * dim)
+        steps = np.zeros((99, dim))
+        for k in range(dim):
+            steps[:, k] = (r == 2 * k + 1).astype(float) - (r == 2 * k + 2)
+        np.testing.assert_array_equal(w, np.vstack([np.zeros(dim), np.cumsum(steps, axis=0)]))
+    nn = 6
+    G = rng.random((nn, nn))
+    U = rng.random(199)
+    got = oracle.random_walkGraph(G, 1, 200, U)
+    pos = 1
+    for i in range(1, 200):
+        p = G[pos] / G[pos].sum()
+        order = np.argsort(-p, kind="stable")
+        cum, j = 0.0, 0
+        for j in range(nn - 1):
+            cum += p[order[j]]
+            if U[i - 1] <= cum:
+                break
+        else:
+            j = nn - 1
+        pos = int(order[j])
+        assert got[i] == pos
