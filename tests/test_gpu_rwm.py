@@ -16,15 +16,33 @@ pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 RTOL = 1e-12
-# One chain per workgroup (12 < d <= 128): the d-term sums are cut into per-thread runs and added as a tree, the
-# reference (and the oracle) add left to right.  Each proposal coordinate then differs by <= ~sqrt(d) eps |terms|, the
-# walk adds one such error per accepted move, and nothing contracts it: d = 100 over 1 000 iterations is a few 1e-13
-# of |theta| (measured: 2e-13 .. 6e-12 over the cases below), above north_star's 1e-12 only by that accumulation.
-BLOCK_RTOL = 1e-11
+# One chain per workgroup / per lane row (d > 12): the d-term sums are cut into per-thread runs and added as a tree, the
+# reference (and the oracle) add left to right, and a random walk accumulates such differences without contracting
+# them.  Measured over every case of this file (profiles/r2_parity_errors.txt, written by MCMC_PARITY_REPORT): at most
+# 3.5e-13 (d = 100, 1 000 iterations); round 1 allowed 1e-11 here without having measured.  north_star's 1e-12 holds.
+BLOCK_RTOL = RTOL
+
+
+_ERRS = {}
 
 
 def _rel(a, b):
-    return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
+    e = float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+    name = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]
+    _ERRS[name] = max(_ERRS.get(name, 0.0), e)
+    return e
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _parity_report():
+    """MCMC_PARITY_REPORT=<file>: the largest trajectory error every test of this module met (DESIGN.md section 4
+    quotes them next to the tolerances)."""
+    yield
+    path = os.environ.get("MCMC_PARITY_REPORT")
+    if path:
+        with open(path, "w") as f:
+            for k in sorted(_ERRS):
+                f.write(f"{_ERRS[k]:.3e}  {k}\n")
 
 
 def _check_decisions(got_acc, ref_diag):
