@@ -140,4 +140,27 @@ __device__ inline void philox_normal2_t(const PhiloxKey &key, uint64_t chain, ui
     z1 = R * (sg * s1);
 }
 
+// One Philox block per lane, either kind: z0, z1 are the two normals of philox_normal2_t for (tag, block) and lg is
+// log(u0) of the block's first uniform -- for (TAG_*_UNIFORM, 0) exactly the log(A) that philox_uniform2 + fm_log_t
+// give.  Lets one wavefront draw the d normals and the uniform of an iteration in ONE pass (no divergent second branch).
+__device__ inline void philox_normal2_log_t(const PhiloxKey &key, uint64_t chain, uint32_t iteration, uint32_t tag,
+                                            uint32_t block, double &z0, double &z1, double &lg, const ScalarCoef<16> &tl,
+                                            const ScalarCoef<16> &ts)
+{
+    const u32x4 b = philox4x32_10((uint32_t)chain, (uint32_t)(chain >> 32), iteration, (tag << 16) | block,
+                                  key.k0, key.k1);
+    const double u0 = u01_from_bits(b.x, b.y);
+    lg = fm_log_t(u0, tl);
+    const double R = fm_sqrt(-2.0 * lg);
+    const uint32_t k = b.z >> 30;
+    const double f = u01_from_bits(b.z << 2 | b.w >> 30, b.w << 2);
+    double s, c;
+    fm_sincospi_quarter_t(0.5 * f - 0.25, s, c, ts);
+    const double s1 = (k & 1) ? c : s;
+    const double c1 = (k & 1) ? -s : c;
+    const double sg = (k & 2) ? -1.0 : 1.0;
+    z0 = R * (sg * c1);
+    z1 = R * (sg * s1);
+}
+
 } // namespace mcmc

@@ -72,10 +72,21 @@ struct BlockLayout {
     __host__ __device__ int pred() const { return ptab() + 3 * kBlockThreads; }
     __host__ __device__ int hq() const { return pred() + 2 * d; }
     __host__ __device__ int total(int TP) const { return hq() + TP * kBlockThreads; }
-    // LDS: R, theta, mean, Y, proposal, v + zero pad, scalars, pivot rows, diag products, per-thread partial sums
-    __host__ __device__ int lds_doubles() const { return T + 5 * d + kVPad + 16 + 2 * (16 * ((d + 15) / 16) + 2) + 16 + kBlockThreads; }
+    // LDS: R, theta, mean, Y of four iterations, proposal, v + zero pad, scalars, pivot rows, diag products, per-thread partial sums
+    __host__ __device__ int lds_doubles() const { return T + 8 * d + kVPad + 16 + 2 * (16 * ((d + 15) / 16) + 2) + 16 + kBlockThreads; }
     static constexpr int kVPad = 64; // zeros after v: a target run may read up to TP + 7 entries past its row's last term
 };
+
+// Length of the runs block_segments (below) cuts rows c = 0..d-1 of c + extra terms into: the smallest S >= min_run
+// that needs no more than kBlockThreads runs.  constexpr: the kernels size their per-thread run registers with it.
+__host__ __device__ constexpr int block_run_length(int d, int extra, int min_run)
+{
+    for (int S = min_run;; ++S) {
+        long runs = 0;
+        for (int c = 0; c < d; ++c) runs += (c + extra + S - 1) / S;
+        if (runs <= kBlockThreads) return S;
+    }
+}
 
 #ifndef __HIPCC_RTC__
 // Cuts rows c = 0..d-1 with len(c) terms each into runs of at most S consecutive terms, S the smallest value that
@@ -87,14 +98,7 @@ struct BlockSegments {
 inline BlockSegments block_segments(int d, int extra, int min_run) // len(c) = c + extra (0: strictly below the diagonal, 1: with it)
 {
     BlockSegments g;
-    for (int S = min_run;; ++S) { // a run shorter than one batch of loads only adds threads, not speed
-        long runs = 0;
-        for (int c = 0; c < d; ++c) runs += (c + extra + S - 1) / S;
-        if (runs <= kBlockThreads) {
-            g.S = S;
-            break;
-        }
-    }
+    g.S = block_run_length(d, extra, min_run); // a run shorter than one batch of loads only adds threads, not speed
     for (int c = 0; c < d; ++c)
         for (int f = 0; f < c + extra; f += g.S) {
             g.row.push_back(c);
@@ -122,14 +126,13 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
     double *const A = lds;        // packed upper factor R, (r,c) r<=c at c(c+1)/2 + r
     double *const th = A + T;     // theta_current
     double *const mn = th + d;    // theta_mean
-    double *const Y = mn + d;     // proposal normals
-    double *const pr = Y + d;     // theta_propose
+    double *const Y4 = mn + d;    // proposal normals of four consecutive iterations (the four waves draw one each)
+    double *const pr = Y4 + 4 * d; // theta_propose
     double *const v = pr + d;     // scratch: x - mean of the target, residual
-    double *const sc = v + d + BlockLayout::kVPad; // v is followed by zeros; sc[0] = log(A); sc[4..7], sc[8..11]: per-wave partial sums
+    double *const sc = v + d + BlockLayout::kVPad; // v is followed by zeros; sc[12..15] = log(A) of four iterations; sc[4..7], sc[8..11]: per-wave partial sums
     double *const raw = sc + 16;  // two unscaled pivot rows (double buffer): 16 NT entries, the pivot, one pad
     constexpr int RS = 16 * NT + 2;
-    double *const pp = raw + 2 * RS; // 16 partial products of diag(R)
-    double *const part = pp + 16;    // per-thread partial sums of the proposal
+    double *const part = raw + 2 * RS + 16; // per-thread partial sums of the proposal; pivots / 1 / R_jj while R is factored
     constexpr int NB = NT * (NT + 1) / 2;
     const int64_t n = a.n_chains;
     // Workgroups go round-robin to the 8 XCDs, each with its own L2, and a chain writes 8 bytes of a 64-byte trace
@@ -152,24 +155,38 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
     const double *__restrict__ Hd = prm + L.hdiag();
     const double *__restrict__ Hq = prm + L.hq();
     // this thread's runs of the target's and the proposal's triangular sums
-    const int TP = __builtin_amdgcn_readfirstlane((int)prm[L.meta()]), SP = __builtin_amdgcn_readfirstlane((int)prm[L.meta() + 1]);
+    const int TP = __builtin_amdgcn_readfirstlane((int)prm[L.meta()]);
     const int t_row = (int)prm[L.ttab() + 2 * tid], t_first = (int)prm[L.ttab() + 2 * tid + 1];
     const int p_col = (int)prm[L.ptab() + 3 * tid], p_first = (int)prm[L.ptab() + 3 * tid + 1], p_len = (int)prm[L.ptab() + 3 * tid + 2];
     const int r_first = tid < d ? (int)prm[L.pred() + 2 * tid] : 0, r_count = tid < d ? (int)prm[L.pred() + 2 * tid + 1] : 0;
     const int ti = tid >> 4, tk = tid & 15; // tile row / column: the 16 owners of a row sit in one wave
 
     // covmat_empirical tile (registers) and the working copy the factorization consumes
-    double Ct[NB], At[NB];
+    // At doubles as W: between factorizations it holds this thread's run of the proposal sum -- SP consecutive entries
+    // of one column of R -- so that an iteration reads only Y from LDS (R changes only when it is refactored)
+    constexpr int WS = block_run_length(16 * NT, 1, 4); // longest proposal run any d of this NT can have
+    constexpr int WN = NB > WS ? NB : WS;
+    double Ct[NB], At[WN];
+    double(&W)[WN] = At;
 #pragma unroll
     for (int q = 0; q < NB; ++q) Ct[q] = 0.0;
+    auto load_runs = [&]() { // after R in LDS changed and a barrier
+#pragma unroll
+        for (int u = 0; u < WN; ++u) W[u] = (p_col >= 0 && u < p_len) ? A[tri(0, p_col) + p_first + u] : 0.0;
+    };
     for (int e = tid; e < T; e += kBlockThreads) A[e] = prm[L.r0() + e];
     if (tid < d) {
         const double x0 = a.d_init ? a.d_init[(int64_t)tid * n + c] : prm[L.init() + tid];
         th[tid] = x0;
         mn[tid] = x0;
+        pr[tid] = 0.0; // the proposal runs multiply up to WS entries from Y + first on, zero coefficients past their end:
+        v[tid] = 0.0;  // what follows a Y in LDS must be finite from the first iteration on (0 * NaN)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Y4[q * d + tid] = 0.0;
     }
     if (tid < BlockLayout::kVPad) v[d + tid] = 0.0;
     __syncthreads();
+    load_runs();
 
     // sum over the wavefront, every lane gets it: four DPP steps inside each row of 16 lanes (no LDS round trip, unlike
     // a shuffle), then the four row totals through scalar registers
@@ -191,6 +208,25 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
         };
         return (row_total(0) + row_total(16)) + (row_total(32) + row_total(48));
+    };
+    auto wave_prod = [](double x) -> double { // the same tree with products
+        auto dpp_mul = [](double y, auto ctrl) -> double {
+            constexpr int C = decltype(ctrl)::value;
+            const uint64_t b = (uint64_t)__double_as_longlong(y);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, C, 0xf, 0xf, false);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), C, 0xf, 0xf, false);
+            return y * __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+        };
+        x = dpp_mul(x, DppCtrl<0xB1>{});
+        x = dpp_mul(x, DppCtrl<0x4E>{});
+        x = dpp_mul(x, DppCtrl<0x141>{});
+        x = dpp_mul(x, DppCtrl<0x140>{});
+        auto row_total = [&](int lane) -> double {
+            const uint64_t b = (uint64_t)__double_as_longlong(x);
+            const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)b, lane), hi = __builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), lane);
+            return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+        };
+        return (row_total(0) * row_total(16)) * (row_total(32) * row_total(48));
     };
     // -0.5 (x - m)^T H (x - m); result replicated in every thread.  An iteration is a chain of latencies, not of
     // flops: a wave alone on its SIMD issues one instruction per ~11 cycles (measured with per-phase clocks at
@@ -292,11 +328,14 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             if (tid < d) th[tid] = __builtin_nan("");
         }
         __syncthreads();
+        load_runs();
     }
 
     // pow(adapt_size_cooling, i - adapt_size_start), fetched one iteration ahead: the adaptation opens the
     // iteration and would otherwise wait for an L2 round trip
     double cool_next = ass != 0 ? a.d_cool_pow[1] : 0.0;
+    int thin_ctr = i0 % a.thin; // i mod thin and the number of rows kept so far, as running counters
+    int64_t t_kept = 0;
     for (int i = i0 + 1; i <= i0 + a.n_iterations; ++i) {
         const int li = i - i0; // position inside this launch: streams, diagnostics and the cooling table are per launch
         const double di = (double)i;
@@ -305,7 +344,8 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
         // ---- adaptation of covmat_proposal (adaptMCMC_source.cpp:117-139), replicated ---------------
         bool rescale = false, refactor = false;
         if (ass != 0 && i >= ass && (ashs == 0 || mul_rn(rate, di) < (double)ashs)) {
-            scaling_multiplier = fm_exp(cool * (rate - 0.234));
+            // polynomial coefficients by one scalar table load at the use (fastmath.h: fm_tab), not 2 s_mov_b32 each
+            scaling_multiplier = fm_exp_t(cool * (rate - 0.234), fm_tab<16>(FT_EXP, i));
             scaling_sd = mul_rn(scaling_sd, scaling_multiplier);
             scaling_sd = (a.max_scaling_sd < scaling_sd) ? a.max_scaling_sd : scaling_sd;
             const double s2 = mul_rn(scaling_sd, scaling_sd);
@@ -327,6 +367,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
                 __syncthreads();
                 for (int e = tid; e < T; e += kBlockThreads) A[e] = prm[L.r0() + e];
                 __syncthreads();
+                load_runs();
                 prodR = prodR0;
                 base_emp = false;
             }
@@ -336,21 +377,22 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
 #pragma unroll
             for (int q = 0; q < NB; ++q) At[q] = Ct[q];
             bool ok = true;
-            double prod = 1.0; // diag(R) entries this thread finished (the owner with tk == 0)
 #pragma unroll
             for (int a0 = 0; a0 < NT; ++a0) {
                 for (int jt = 0; jt < 16; ++jt) {
                     const int j = 16 * a0 + jt;
                     if (j >= d) break;
                     double *const row = raw + (j & 1) * RS;
-                    const bool owner = ti == jt;
-                    if (owner) { // publish row j: zero up to and including the pivot, so that readers need no range test
+                    if (ti == jt) { // publish row j: zero up to and including the pivot, so that readers need no range test
 #pragma unroll
                         for (int bb = a0; bb < NT; ++bb) {
-                            const int kk = 16 * bb + tk;
                             const double val = At[blk(a0, bb)]; // entries beyond d are exactly zero
-                            if (kk == j) row[16 * NT] = val;
-                            row[kk] = (kk > j) ? val : 0.0;
+                            if (bb == a0) {
+                                if (tk == jt) row[16 * NT] = val;
+                                row[16 * bb + tk] = (tk > jt) ? val : 0.0;
+                            } else {
+                                row[16 * bb + tk] = val;
+                            }
                         }
                     }
                     __syncthreads();
@@ -363,18 +405,15 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
                         ri[x] = row[16 * x + ti] * inv;
                         rk[x] = row[16 * x + tk];
                     }
-                    if (owner) { // finished row j of R -> LDS (packed by columns)
-                        double rjj, rinv;
-                        fm_sqrt_rsq(ajj, rjj, rinv);
-#pragma unroll
-                        for (int bb = a0; bb < NT; ++bb) {
-                            const int kk = 16 * bb + tk;
-                            if (kk > j && kk < d) A[tri(j, kk)] = rk[bb] * rinv;
-                            if (kk == j) {
-                                A[tri(j, j)] = rjj;
-                                prod *= rjj;
-                            }
-                        }
+                    // Row j of the factor goes to its place in A UNSCALED, one entry per thread of the first waves, and
+                    // the pivot to part[j]: the square roots and the scaling by 1 / R_jj wait until all pivots are done.
+                    // (With the owners finishing their row here -- square root, NT scaled stores -- one wave ran ~60
+                    // instructions more than the others at every pivot, and the barrier waited for it: 32 % of a
+                    // shape-phase run at d = 100, measured.)
+                    {
+                        const int kk = 16 * a0 + tid;
+                        if (tid < 16 * (NT - a0) && kk > j && kk < d) A[tri(j, kk)] = row[kk];
+                        if (tid == 0) part[j] = ajj;
                     }
 #pragma unroll
                     for (int bb = a0; bb < NT; ++bb) {
@@ -383,12 +422,35 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
                     }
                 }
             }
-            if (tk == 0) pp[ti] = prod;
             __syncthreads();
-            prod = 1.0;
-            for (int q = 0; q < 16; ++q) prod *= pp[q];
+            {   // R_jj = sqrt(pivot_j), all rows at once; part[j] becomes 1 / R_jj
+                double rjj = 1.0;
+                if (tid < d) {
+                    double rinv;
+                    fm_sqrt_rsq(part[tid], rjj, rinv);
+                    A[tri(tid, tid)] = rjj;
+                    part[tid] = rinv;
+                }
+                const double wp = wave_prod(rjj);
+                if ((tid & 63) == 0) sc[4 + (tid >> 6)] = wp;
+            }
             __syncthreads();
-            prodR = prod;
+            prodR = (sc[4] * sc[5]) * (sc[6] * sc[7]);
+            // scale the rows; every thread takes the run of its proposal sum and keeps it in registers (W)
+#pragma unroll
+            for (int u = 0; u < WN; ++u) {
+                double val = 0.0;
+                if (p_col >= 0 && u < p_len) {
+                    double *const e = A + tri(0, p_col) + p_first + u;
+                    val = *e;
+                    if (p_first + u != p_col) { // the diagonal entry is finished
+                        val *= part[p_first + u];
+                        *e = val;
+                    }
+                }
+                W[u] = val;
+            }
+            __syncthreads();
             base_emp = true;
             s_eff = scaling_sd;
             if (!ok) { // arma::chol throws here; the chain stops and reports where
@@ -423,41 +485,50 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
         }
 
         // ---- draws: d normals, then one uniform (:149-152,174) ----------------------------------------
+        const int slot = inject ? 0 : ((li - 1) & 3);
+        double *const Y = Y4 + slot * d;
         if (inject) {
             if (tid < d) Y[tid] = a.d_Z[((int64_t)(li - 1) * d + tid) * n + c];
-            if (tid == 0) sc[0] = fm_log<true>(a.d_U[(int64_t)(li - 1) * n + c]);
-        } else {
-            const int nb = (d + 1) / 2;
-            if (tid < nb) {
-                double z0, z1;
-                philox_normal2(key, gchain, (uint32_t)i, TAG_RWM_NORMAL, (uint32_t)tid, z0, z1);
-                Y[2 * tid] = z0;
-                if (2 * tid + 1 < d) Y[2 * tid + 1] = z1;
-            } else if (tid == nb) {
-                double u0, u1;
-                philox_uniform2(key, gchain, (uint32_t)i, TAG_RWM_UNIFORM, 0u, u0, u1);
-                sc[0] = fm_log<true>(u0);
+            if (tid == 0) sc[12] = fm_log<true>(a.d_U[(int64_t)(li - 1) * n + c]);
+            __syncthreads();
+        } else if (slot == 0) {
+            // Every fourth iteration the four waves draw for four iterations, wave w for iteration i + w: a Philox block
+            // and a Box-Muller pair are ~200 dependent instructions whichever lanes take part (13 % of an iteration at
+            // d = 100 when one wave drew every iteration and three waited; measured).  Lane l < nb draws normals 2l,
+            // 2l + 1, lane nb the uniform -- the same code: log(u0) is the first step of Box-Muller.
+            const int wv = tid >> 6, ln = tid & 63, nb = (d + 1) / 2;
+            PhiloxKey kk = key; // opaque copy: the round keys are formed by scalar adds here, not hoisted and spilled
+            asm volatile("" : "+s"(kk.k0), "+s"(kk.k1));
+            const ScalarCoef<16> tl = fm_tab<16>(FT_LOG, i), ts = fm_tab<16>(FT_SINCOS, i);
+            const uint32_t it = (uint32_t)(i + wv); // past the last iteration of the launch: drawn, never used
+            double *const Yw = Y4 + wv * d;
+            if (ln <= nb) {
+                const bool uni = ln == nb;
+                double z0, z1, lg;
+                philox_normal2_log_t(kk, gchain, it, uni ? TAG_RWM_UNIFORM : TAG_RWM_NORMAL, uni ? 0u : (uint32_t)ln, z0, z1, lg, tl, ts);
+                if (uni) {
+                    sc[12 + wv] = lg;
+                } else {
+                    Yw[2 * ln] = z0;
+                    if (2 * ln + 1 < d) Yw[2 * ln + 1] = z1;
+                }
             }
+            if (nb == 64 && ln == 0) { // d = 127, 128: the 64 lanes are all taken by normals
+                double z0, z1, lg;
+                philox_normal2_log_t(kk, gchain, it, TAG_RWM_UNIFORM, 0u, z0, z1, lg, tl, ts);
+                sc[12 + wv] = lg;
+            }
+            __syncthreads();
         }
-        __syncthreads();
 
         // ---- proposal theta + Y * R (:153-154): one run of consecutive k of one column per thread, then the runs
         // of a column are added in order by its thread ------------------------------------------------------------
         {
             double s = 0.0;
-            if (p_col >= 0) {
-                const double *const col = A + tri(0, p_col) + p_first;
+            if (p_col >= 0) { // W is zero past the run; the Y read there is some finite entry of this workgroup's LDS
                 const double *const yp = Y + p_first;
-                for (int u = 0; u < SP; u += 4) { // reads past the run stay inside the workgroup's LDS and are not used
-                    double r[4], y[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        r[q] = col[u + q];
-                        y[q] = yp[u + q];
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) s = (u + q < p_len) ? fma(y[q], r[q], s) : s;
-                }
+                for (int u = 0; u < WS; ++u) s = fma(yp[u], W[u], s);
             }
             part[tid] = s;
             // |Y|^2 for the Hastings term
@@ -471,7 +542,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
                 pr[tid] = th[tid] + s_eff * t;
             }
         }
-        const double logA = sc[0];
+        const double logA = sc[12 + slot];
         __syncthreads();
         const double q = (sc[8] + sc[9]) + (sc[10] + sc[11]);
 
@@ -482,7 +553,11 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             la = -__builtin_inf();
         } else {
             la = t_prop - t_cur;
-            const double p = fm_log<true>(rootTerm * fm_exp(-0.5 * q));
+            const double pe = rootTerm * fm_exp_t(-0.5 * q, fm_tab<16>(FT_EXP, li));
+            double p = fm_log_t(pe, fm_tab<16>(FT_LOG, li));
+            p = (pe == 0.0) ? -__builtin_inf() : p; // the special cases of fm_log<true>: the NaN-reject path needs them
+            p = (pe < 0.0 || pe != pe) ? __builtin_nan("") : p;
+            p = (pe == __builtin_inf()) ? pe : p;
             la = add_rn(la, p);
             la = add_rn(la, -p);
         }
@@ -499,8 +574,12 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
         __syncthreads();
 
         // ---- trace (:185) -------------------------------------------------------------------------------
-        const bool keep = (i % a.thin) == 0;
-        const int64_t t = i / a.thin - i0 / a.thin - 1; // row inside this launch's trace
+        const bool keep = ++thin_ctr == a.thin; // i % thin == 0, without a division per iteration
+        const int64_t t = t_kept;               // row inside this launch's trace
+        if (keep) {
+            thin_ctr = 0;
+            ++t_kept;
+        }
         if (a.d_trace && keep && tid < d) a.d_trace[(t * d + tid) * n + c] = th[tid];
 
         // ---- acceptance rate (:188-207), replicated ------------------------------------------------------
