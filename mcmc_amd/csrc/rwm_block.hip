@@ -234,6 +234,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
     // number of instructions per term and per thread.  Each thread owns one run of consecutive terms of one row
     // (block_segments): its coefficients come coalesced from L2, eight loads in flight, the v entries from LDS at
     // constant offsets, one FMA per term; one wave reduction plus four partial sums in LDS finish the sum.
+    // Precondition: a barrier since v[k] = x[k] - mean[k] (USER: x[k]) was stored by thread k for every k < d.
     auto target = [&](const double *x) -> double {
         if constexpr (USER) { // every thread one part of the user's sum; x (theta or the proposal) is complete in LDS
 #ifdef MCMC_USER_BLOCK
@@ -245,8 +246,6 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             return 0.0;
 #endif
         }
-        if (tid < d) v[tid] = x[tid] - tmean[tid];
-        __syncthreads();
         double acc = 0.0;
         if (t_row >= 0) {
             const double *const vp = v + t_first;
@@ -280,6 +279,8 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
     const double prodR0 = prodR;
     bool base_emp = false; // R holds chol(covmat_empirical)
     double s_eff = 1.0;    // covmat_proposal = s_eff^2 R^T R
+    if (!USER && tid < d) v[tid] = th[tid] - tmean[tid];
+    __syncthreads();
     double t_cur = target(th);
     double rate = 0.0, scaling_sd = 1.0, scaling_multiplier = 1.0;
     AcceptWindow win; // replicated in every thread, like the other scalars of the chain; thread 0 stores the ring words
@@ -536,15 +537,17 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             const double ys = wave_sum(yy);
             if ((tid & 63) == 0) sc[8 + (tid >> 6)] = ys;
             __syncthreads();
-            if (tid < d) {
+            if (tid < d) { // thread k is the only one that touches theta[k], proposal[k] and writes v[k]
                 double t = part[r_first];
                 for (int q = 1; q < r_count; ++q) t += part[r_first + q];
-                pr[tid] = th[tid] + s_eff * t;
+                const double p = th[tid] + s_eff * t;
+                pr[tid] = p;
+                if (!USER) v[tid] = p - tmean[tid];
             }
         }
         const double logA = sc[12 + slot];
-        __syncthreads();
         const double q = (sc[8] + sc[9]) + (sc[10] + sc[11]);
+        __syncthreads();
 
         // ---- target and Metropolis-Hastings log ratio (:157-171) --------------------------------------
         const double t_prop = target(pr);
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             if (a.d_log_acceptance) a.d_log_acceptance[(int64_t)(li - 1) * n + c] = la;
             if (a.d_log_A) a.d_log_A[(int64_t)(li - 1) * n + c] = logA;
         }
-        __syncthreads();
+        // no barrier: theta[k], theta_mean[k] and proposal[k] are read and written by thread k alone
 
         // ---- trace (:185) -------------------------------------------------------------------------------
         const bool keep = ++thin_ctr == a.thin; // i % thin == 0, without a division per iteration
@@ -631,7 +634,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
                     }
                 }
             }
-            __syncthreads();
+            // no barrier: v is next written after the first barrier of the next iteration's proposal
         }
     }
 
