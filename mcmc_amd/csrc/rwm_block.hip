@@ -56,7 +56,8 @@ __host__ __device__ constexpr int blk(int a, int b) { return b * (b + 1) / 2 + a
 //   sum_{k<=c} Y_k R_kc -- are cut into runs of consecutive i (k) of one row (column), at most TP (SP) long, one run
 //   per thread (block_segments): ttab[tid] = (row, first i), ptab[tid] = (column, first k, length), -1 = no run;
 //   pred[c] = (first thread, number of threads) of column c.  Hq[t][tid] is the coefficient of term t of thread
-//   tid's target run, zero beyond its end.  meta = (TP, SP).
+//   tid's target run, zero beyond its end.  meta = (TP, KL): the first KL rows of Hq are copied into LDS by every
+//   workgroup (as many as the CU's LDS holds beside the chains' own state), the rest is read from L2.
 struct BlockLayout {
     int d, T;
     __host__ __device__ explicit BlockLayout(int d_) : d(d_), T(d_ * (d_ + 1) / 2) {}
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
     double *const raw = sc + 16;  // two unscaled pivot rows (double buffer): 16 NT entries, the pivot, one pad
     constexpr int RS = 16 * NT + 2;
     double *const part = raw + 2 * RS + 16; // per-thread partial sums of the proposal; pivots / 1 / R_jj while R is factored
+    double *const Hl = part + kBlockThreads; // the first KL rows of Hq, [t][thread]
     constexpr int NB = NT * (NT + 1) / 2;
     const int64_t n = a.n_chains;
     // Workgroups go round-robin to the 8 XCDs, each with its own L2, and a chain writes 8 bytes of a 64-byte trace
@@ -155,7 +157,9 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
     const double *__restrict__ Hd = prm + L.hdiag();
     const double *__restrict__ Hq = prm + L.hq();
     // this thread's runs of the target's and the proposal's triangular sums
-    const int TP = __builtin_amdgcn_readfirstlane((int)prm[L.meta()]);
+    // Hq rows in LDS for NT = 3 .. 6 (below: the row kernel serves production and the runs are two loads long): the 256 registers of the NT = 7, 8 kernels are full, and the extra loop spills
+    // (d = 100: 4.80 ms against 4.21 per 100 iterations of 4 096 chains, measured)
+    const int TP = __builtin_amdgcn_readfirstlane((int)prm[L.meta()]), KL = (NT >= 3 && NT <= 6) ? __builtin_amdgcn_readfirstlane((int)prm[L.meta() + 1]) : 0;
     const int t_row = (int)prm[L.ttab() + 2 * tid], t_first = (int)prm[L.ttab() + 2 * tid + 1];
     const int p_col = (int)prm[L.ptab() + 3 * tid], p_first = (int)prm[L.ptab() + 3 * tid + 1], p_len = (int)prm[L.ptab() + 3 * tid + 2];
     const int r_first = tid < d ? (int)prm[L.pred() + 2 * tid] : 0, r_count = tid < d ? (int)prm[L.pred() + 2 * tid + 1] : 0;
@@ -185,6 +189,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
         for (int q = 0; q < 4; ++q) Y4[q * d + tid] = 0.0;
     }
     if (tid < BlockLayout::kVPad) v[d + tid] = 0.0;
+    for (int t = 0; t < KL; ++t) Hl[t * kBlockThreads + tid] = Hq[t * kBlockThreads + tid];
     __syncthreads();
     load_runs();
 
@@ -251,7 +256,32 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             const double *const vp = v + t_first;
             const double *const hp = Hq + tid;
             constexpr int CH = NT <= 4 ? 4 : 8; // loads in flight; small d: short runs, and the registers decide the occupancy
-            for (int t = 0; t < TP; t += CH) {
+            // Coefficients KL .. KL + CH - 1 are requested from L2 first and used last; the rows before them sit in LDS
+            // (the L2 round trips of this sum, TP / CH of them, were 19 % of an iteration at d = 100; measured)
+            int t_l2 = 0;
+            if constexpr (NT >= 3 && NT <= 6) {
+                double hl[CH];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) hl[u] = (KL + u < TP) ? hp[(KL + u) * kBlockThreads] : 0.0;
+                const double *const hs = Hl + tid;
+                for (int t = 0; t < KL; t += 4) { // KL is a multiple of 4
+                    double h[4], vv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        h[u] = hs[(t + u) * kBlockThreads];
+                        vv[u] = vp[t + u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = fma(h[u], vv[u], acc);
+                }
+                double vv[CH];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) vv[u] = vp[KL + u];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) acc = fma(hl[u], vv[u], acc);
+                t_l2 = KL + CH;
+            }
+            for (int t = t_l2; t < TP; t += CH) {
                 double h[CH], vv[CH];
 #pragma unroll
                 for (int u = 0; u < CH; ++u) h[u] = (t + u < TP) ? hp[(t + u) * kBlockThreads] : 0.0;
@@ -732,7 +762,7 @@ int launch_rwm_block_with(const RwmArgs &a, const RwmParams &p, hipStream_t s, b
     if (!user && (int)p.tparams.size() != d + d * d) return set_error(MCMC_E_BAD_ARG, "gaussian target needs d + d*d parameters");
     const BlockLayout L(d);
     const BlockSegments tseg = user ? BlockSegments{} : block_segments(d, 0, 8), pseg = block_segments(d, 1, 4);
-    const int TP = tseg.S > 0 ? tseg.S : 1, SP = pseg.S;
+    const int TP = tseg.S > 0 ? tseg.S : 1;
     if (TP + 7 > BlockLayout::kVPad + 1) return set_error(MCMC_E_UNSUPPORTED, "adaptive RWM: d=%d needs a longer zero pad", d);
     std::vector<double> blob(user ? (size_t)L.hq() + p.tparams.size() + 1 : (size_t)L.total(TP), 0.0);
     for (int k = 0; k < d; ++k) blob[L.init() + k] = p.init[k];
@@ -748,7 +778,11 @@ int launch_rwm_block_with(const RwmArgs &a, const RwmParams &p, hipStream_t s, b
     }
     for (size_t e = 0; e < p.tparams.size() && user; ++e) blob[L.hq() + e] = p.tparams[e];
     blob[L.meta()] = TP;
-    blob[L.meta() + 1] = SP;
+    // rows of Hq in LDS: what is left of a CU's 160 KB beside the state of the chains it holds (launch bounds: 4 / 3 / 2)
+    const int nt_ = (d + 15) / 16, per_cu = nt_ <= 2 ? 4 : (nt_ <= 4 ? 3 : 2);
+    const long free_doubles = (160 * 1024 / per_cu - 1024) / 8 - L.lds_doubles();
+    const int KL = (user || nt_ < 3 || nt_ > 6) ? 0 : (int)std::max(0L, std::min<long>(TP, free_doubles / kBlockThreads)) & ~3;
+    blob[L.meta() + 1] = KL;
     for (int tid = 0; tid < kBlockThreads; ++tid) {
         const bool ht = tid < (int)tseg.row.size(), hp = tid < (int)pseg.row.size();
         blob[L.ttab() + 2 * tid] = ht ? tseg.row[tid] : -1;
@@ -771,7 +805,7 @@ int launch_rwm_block_with(const RwmArgs &a, const RwmParams &p, hipStream_t s, b
     MCMC_HIP_CHECK(hipMallocAsync((void **)&d_prm, blob.size() * sizeof(double), s));
     MCMC_HIP_CHECK(hipMemcpyAsync(d_prm, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, s));
     MCMC_HIP_CHECK(hipStreamSynchronize(s)); // blob is a local: do not let the copy outlive it
-    const size_t ldsb = (size_t)L.lds_doubles() * sizeof(double);
+    const size_t ldsb = ((size_t)L.lds_doubles() + (size_t)KL * kBlockThreads) * sizeof(double);
     const bool full = a.d_Z || a.d_sigma_trace || a.d_accepted || a.d_log_acceptance || a.d_log_A || a.d_scaling_sd ||
                       a.d_scaling_multiplier || a.d_rate_trace;
     hipError_t e1 = launch(full ? 1 : 0, (unsigned)a.n_chains, (unsigned)kBlockThreads, ldsb, s, a, d_prm);
