@@ -1,0 +1,18 @@
+#!/bin/bash
+# The round's record runs: every bench.py workload (with the CPU baseline leg) -> gpurun_out/<tag>_<wl>_bench.json,
+# then the block / row kernel microbenchmarks.  Usage (GPU box): bash tools/bench_all.sh r2
+set -e
+tag=$1
+cd "$(dirname "$0")/.."
+out=gpurun_out
+timeout -k 10 200 python3 bench.py > $out/${tag}_c2_bench.json
+timeout -k 10 200 python3 bench.py --workload c3 > $out/${tag}_c3_bench.json
+timeout -k 10 200 python3 bench.py --workload c5 > $out/${tag}_c5_bench.json
+timeout -k 10 300 python3 bench.py --workload c4 --steps 2 --warmup 1 > $out/${tag}_c4_bench.json
+timeout -k 10 400 python3 bench.py --workload c4s --steps 2 --warmup 1 > $out/${tag}_c4s_bench.json
+: > $out/${tag}_microbench_block.txt
+for m in block block_mid shape mid; do
+    echo "## tools/microbench.py $m" >> $out/${tag}_microbench_block.txt
+    timeout -k 10 280 python3 tools/microbench.py $m 2>&1 | grep -v amdgpu.ids >> $out/${tag}_microbench_block.txt
+done
+echo done
