@@ -343,7 +343,8 @@ def test_init_normal_and_argument_validation(cuda):
         mcmc_amd.adapt_rwm_batch(mcmc_amd.Target.goldstein_price(), 4, np.zeros(3), np.eye(3), 10)  # d != 2
 
 
-@pytest.mark.parametrize("d,n,kernel,ass,ashs", [(10, 800, "block", 50, 120), (24, 500, "auto", 40, 90), (100, 1000, "auto", 20, 160)])
+@pytest.mark.parametrize("d,n,kernel,ass,ashs", [(10, 800, "block", 50, 120), (24, 500, "auto", 40, 90), (48, 600, "auto", 25, 70),
+                                                 (63, 700, "auto", 25, 90), (100, 1000, "auto", 20, 160), (128, 900, "auto", 20, 150)])
 def test_block_kernel_matches_oracle(cuda, oracle, d, n, kernel, ass, ashs):
     """One chain per 256-thread workgroup (12 < d <= 128; forced at d = 10 to compare the two kernels)."""
     import mcmc_amd
