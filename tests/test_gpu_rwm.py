@@ -19,7 +19,8 @@ RTOL = 1e-12
 # One chain per workgroup / per lane row (d > 12): the d-term sums are cut into per-thread runs and added as a tree, the
 # reference (and the oracle) add left to right, and a random walk accumulates such differences without contracting
 # them.  Measured over every case of this file (profiles/r2_parity_errors.txt, written by MCMC_PARITY_REPORT): at most
-# 3.5e-13 (d = 100, 1 000 iterations); round 1 allowed 1e-11 here without having measured.  north_star's 1e-12 holds.
+# 7.4e-13 (d = 63, 700 iterations; 3.5e-13 at d = 100 over 1 000); round 1 allowed 1e-11 here without having measured.
+# north_star's 1e-12 holds.
 BLOCK_RTOL = RTOL
 
 
