@@ -6,8 +6,8 @@
 //
 // Data placement per chain (= per workgroup of four wavefronts, one per SIMD of a CU):
 //   * R, the upper Cholesky factor of covmat_proposal, packed by columns, in LDS (T = d(d+1)/2
-//     doubles) together with theta, theta_mean, the normals Y, the proposal and two scratch vectors:
-//     45 KB at d = 100, so three chains share the 160 KB of a CU (12 waves, 3 per SIMD);
+//     doubles) together with theta, theta_mean, the normals Y of four iterations, the proposal and two scratch
+//     vectors: 51 KB at d = 100; the registers (two copies of the 28-tile matrix) allow two chains per CU there;
 //   * covmat_empirical in REGISTERS, 2-D cyclic over the 16 x 16 threads: thread (ti, tk) owns the
 //     elements (16a + ti, 16b + tk), a <= b, of the upper triangle (NT(NT+1)/2 doubles, NT = ceil(d/16)).
 //     It is only ever touched element-wise (the rank-1 update_sigma), and the factorization works
@@ -26,8 +26,9 @@
 // registers: at step j the owners of row j (a quarter of ONE wave) publish it in a double-buffered
 // LDS row -- unscaled, zero up to the pivot, the pivot in a slot of its own -- ONE barrier, then every
 // thread reads the 2 NT entries it needs without any range test, scales one side by 1/pivot and
-// updates its tile with at most NT(NT+1)/2 FMAs (a_ik - (a_ji / a_jj) a_jk: the square root is off the
-// critical path); the owners alone take the square root and store the finished row of R to LDS.
+// updates its tile with at most NT(NT+1)/2 FMAs (a_ik - (a_ji / a_jj) a_jk).  No square root is taken
+// inside the loop: the unscaled rows and the pivots are kept, and all d square roots and the scaling of
+// the rows by 1 / R_jj are done once, in parallel, after the last pivot.
 // The step is instruction-bound, so what counts is the number of instructions around the FMAs.
 #ifndef __HIPCC_RTC__
 #include <algorithm>
