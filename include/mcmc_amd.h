@@ -74,9 +74,9 @@ extern "C" {
                                 Gaussian target only                                               */
 #define MCMC_KERNEL_PAIR 3   /* one chain per lane, a sampler and a generator wavefront per 64 chains;
                                 Philox streams, no per-iteration diagnostics, d <= 10              */
-#define MCMC_KERNEL_ROW 4    /* one chain per row of 16 (d <= 16) or 32 lanes (d <= 32) of a wavefront, one coordinate
+#define MCMC_KERNEL_ROW 4    /* one chain per row of 16 (d <= 16), 32 (d <= 32) or 64 lanes (d <= 64) of a wavefront, one coordinate
                                 and one matrix column per lane; Gaussian target, Philox streams, no per-iteration
-                                diagnostics.  What AUTO runs for 12 < d <= 32 when it serves the request   */
+                                diagnostics.  What AUTO runs for 12 < d <= 64 when it serves the request   */
 
 /* ----- target log-densities --------------------------------------------------------- */
 /*

@@ -239,7 +239,7 @@ extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_co
     // AUTO picks between the two one-chain-per-lane kernels by what the call asks for (diagnostics, injected streams and
     // windows above 64 outcomes need the one-wave kernel).  A checkpoint is in its writer's representation, so a resumed
     // AUTO run goes back to the kernel named in the state, or is refused here if that kernel cannot serve the request.
-    // 12 < d <= 32: one chain per 16 / 32 lanes where that kernel serves the call (Philox, no diagnostics), else per workgroup
+    // 12 < d <= 64: one chain per 16 / 32 / 64 lanes where that kernel serves the call (Philox, no diagnostics), else per workgroup
     bool use_row = cfg->kernel == MCMC_KERNEL_ROW || (cfg->kernel == MCMC_KERNEL_AUTO && use_block && rwm_row_serves(a, target->kind));
     if (cfg->kernel == MCMC_KERNEL_AUTO && use_block && a.d_state_in) { // a checkpoint goes back to its writer
         double tag = 0.0;

@@ -28,7 +28,7 @@ constexpr int kMaxDimGibbs = 256;
 constexpr int kGibbsLaneMaxDim = 27;
 constexpr int kMaxDimRwm = 128;
 // largest d of the one-chain-per-row kernel (a chain on 16 or 32 lanes of a wavefront, rwm_row.hip)
-constexpr int kMaxRowDimRwm = 32;
+constexpr int kMaxRowDimRwm = 64;
 
 #ifndef __HIPCC_RTC__
 int set_error(int code, const char *fmt, ...);

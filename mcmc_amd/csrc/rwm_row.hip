@@ -1,4 +1,4 @@
-// Adaptive random-walk Metropolis for 12 < d <= 32: one chain per ROW of 16 (d <= 16) or 32 lanes (gfx950).
+// Adaptive random-walk Metropolis for 12 < d <= 64: one chain per ROW of 16 (d <= 16), 32 (d <= 32) or 64 lanes (gfx950).
 //
 // Replaces the main loop of adaptMCMC / rwMCMC (adaptMCMC_source.cpp:108-216, :252-313) in the range where the chain
 // state no longer fits one lane (the factor R and covmat_empirical are 136 doubles each at d = 16, 528 at d = 32) but
@@ -16,7 +16,8 @@
 //     Cholesky   right-looking, in place in the R registers: at pivot p every lane scales its entry of row p, and
 //                the trailing update a_ij -= R_pi R_pj is one such instruction per remaining row i
 // For 32-lane rows the operand is first spread over both 16-lane halves by v_permlane16_swap_b32 (two instructions
-// give "lanes 0-15 of the chain in both halves" and "lanes 16-31 in both halves").  Scalars of a chain (acceptance
+// give "lanes 0-15 of the chain in both halves" and "lanes 16-31 in both halves"); for 64-lane rows -- one chain per
+// wavefront -- v_permlane32_swap_b32 adds the other half, and covmat_empirical moves to LDS (see RowLayout).  Scalars of a chain (acceptance
 // rate, scaling_sd, target value, ...) are computed redundantly, bit-identically, in every lane of its row.
 //
 // chol(s^2 Sigma) = s chol(Sigma): as in the other kernels R is the UNSCALED factor and the scale is kept apart,
@@ -254,8 +255,66 @@ struct RowVec<32> {
     }
 };
 
+// 64-lane rows (one chain per wavefront): four registers, v[r] = the values of lanes 16 r .. 16 r + 15 of the chain in
+// every 16-lane row -- v_permlane16_swap_b32 pairs the rows inside each half, v_permlane32_swap_b32 the halves.
+template <>
+struct RowVec<64> {
+    double v[4];
+    __device__ __forceinline__ explicit RowVec(double x)
+    {
+        const uint64_t u = (uint64_t)__double_as_longlong(x);
+        uint32_t w[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t t = (uint32_t)(u >> (32 * h));
+            const auto a = __builtin_amdgcn_permlane16_swap(t, t, false, false); // a[0] = rows (0,0,2,2), a[1] = rows (1,1,3,3)
+            const auto e = __builtin_amdgcn_permlane32_swap(a[0], a[0], false, false); // e[0] = rows (0,0,0,0), e[1] = (2,2,2,2)
+            const auto o = __builtin_amdgcn_permlane32_swap(a[1], a[1], false, false); // o[0] = rows (1,1,1,1), o[1] = (3,3,3,3)
+            w[h][0] = e[0];
+            w[h][1] = o[0];
+            w[h][2] = e[1];
+            w[h][3] = o[1];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = __longlong_as_double((long long)(((uint64_t)w[1][r] << 32) | w[0][r]));
+        asm volatile("s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+    }
+    template <int K>
+    __device__ __forceinline__ void fmac(double &acc, double y) const { fmac_rb<K % 16>(acc, v[K / 16], y); }
+    template <int K>
+    __device__ __forceinline__ double get() const { return row_bcast<K % 16>(v[K / 16]); }
+    template <int G>
+    __device__ __forceinline__ void dot8(double &acc, const double *m) const { fmac_dot8<G % 2>(acc, v[G / 2], m); }
+    __device__ __forceinline__ void rows(double (&a)[64], double y) const
+    {
+        fmac_rows16(a, v[0], y);
+        fmac_rows16(a + 16, v[1], y);
+        fmac_rows16(a + 32, v[2], y);
+        fmac_rows16(a + 48, v[3], y);
+    }
+    // a[16 B + k] += v_{16 B + k} y, k = 0..15: one block of sixteen rows
+    template <int B>
+    __device__ __forceinline__ void rows16(double *a16, double y) const { fmac_rows16(a16, v[B], y); }
+    // rows P .. d - 1 (whole groups of four; whole blocks of sixteen are skipped once they lie past d)
+    template <int P>
+    __device__ __forceinline__ void rows_from(double (&a)[64], double y, int d) const
+    {
+        row_unroll<0, 4>([&](auto bc) {
+            constexpr int B = decltype(bc)::value;
+            if constexpr (P / 16 <= B) {
+                if (16 * B < d) { // uniform
+                    row_unroll<0, 4>([&](auto gc) {
+                        constexpr int G = 4 * B + decltype(gc)::value;
+                        if constexpr (P / 4 <= G) fmac_rows4<G % 4>(a + 16 * B, v[B], y);
+                    });
+                }
+            }
+        });
+    }
+};
+
 // sum over the lanes of a chain's row, the same bits in every lane: four DPP steps inside a 16-lane row (the pairs are
-// symmetric, and IEEE addition is commutative), then the two halves of a 32-lane row
+// symmetric, and IEEE addition is commutative), then the two halves of a 32-lane row / the four rows of a 64-lane one
 template <int L>
 __device__ __forceinline__ double row_sum(double x)
 {
@@ -274,24 +333,39 @@ __device__ __forceinline__ double row_sum(double x)
         const RowVec<32> v(x);
         x = v.lo + v.hi;
     }
+    if constexpr (L == 64) {
+        const RowVec<64> v(x);
+        x = (v.v[0] + v.v[1]) + (v.v[2] + v.v[3]);
+    }
     return x;
 }
 
 // parameter block (doubles), staged in LDS: min diag(covmat), prod diag(R0), -, -, tmean[L], init[L],
 // Hs[k][j] = (H_jk + H_kj) / 2 (zero beyond d), R0c[k][j] = chol(covmat)_kj for k <= j < d (zero elsewhere)
+//
+// L = 64 (one chain per wavefront, 32 < d <= 64): the R columns alone are 128 registers, so covmat_empirical lives in
+// LDS, per chain, as block columns: lane j = 16 m + q keeps rows 0 .. 16 (m + 1) - 1 of its column (the upper triangle
+// rounded up to whole 16-row blocks; the few entries below the diagonal are the symmetric ones and are kept up to date
+// like the rest), row k at block m's base + 16 k + q -- consecutive lanes, consecutive doubles.  256 m (m + 1) / 2 doubles
+// up to block m: 20 KB per chain at d = 64.  chol(covmat) stays in HBM / L2 (read at start and when the size phase
+// comes back), the workgroup is as many wavefronts as the CU's LDS holds chains (6 at d = 64, 8 up to d = 48).
 template <int L>
 struct RowLayout {
     static constexpr int MINVAR = 0, PROD0 = 1, TMEAN = 4, INIT = 4 + L, HS = 4 + 2 * L, R0 = HS + L * L, TOTAL = R0 + L * L;
-    static constexpr int CPW = 256 / L; // chains per workgroup
-    static constexpr int lds_doubles(int d) { return TOTAL + 2 * d * CPW; }
+    static constexpr int STAGED = L == 64 ? R0 : TOTAL; // the part of the block every workgroup copies into LDS
+    static constexpr int CPW = 256 / L; // chains per workgroup (L = 64: chosen at launch)
+    static constexpr int csize(int d) { return L == 64 ? 128 * ((d + 15) / 16) * ((d + 15) / 16 + 1) : 0; } // covmat_empirical of one chain
+    static constexpr int lds_doubles(int d, int cpw) { return STAGED + cpw * csize(d) + 2 * d * cpw; }
 };
 
 template <int L, bool STATE>
-__global__ __launch_bounds__(256, L == 16 ? 3 : 2) void rwm_row_kernel(const RwmArgs a, const double *__restrict__ prm)
+__global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 3 : (L == 32 ? 2 : 1)) void rwm_row_kernel(const RwmArgs a, const double *__restrict__ prm)
 {
     using Lay = RowLayout<L>;
-    constexpr int CPW = Lay::CPW, RPW = 64 / L;
+    constexpr int RPW = 64 / L;
+    constexpr bool CL = L == 64; // covmat_empirical in LDS
     extern __shared__ double lds[];
+    const int NTHR = CL ? (int)blockDim.x : 256, CPW = CL ? (int)(blockDim.x >> 6) : Lay::CPW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & (L - 1);       // this lane's coordinate
     const int cl = wave * RPW + lane / L; // this lane's chain inside the workgroup
@@ -309,20 +383,37 @@ __global__ __launch_bounds__(256, L == 16 ? 3 : 2) void rwm_row_kernel(const Rwm
     const bool need_moments = ashs != 0 || a.d_final_mean || a.d_final_cov || (STATE && (a.d_state_in || a.d_state_out));
     const int i0 = STATE ? a.iter_offset : 0;
 
-    for (int e = tid; e < Lay::TOTAL; e += 256) lds[e] = prm[e];
+    for (int e = tid; e < Lay::STAGED; e += NTHR) lds[e] = prm[e];
+    const int MB = (d + 15) >> 4, mj = j >> 4; // 16-row blocks of the matrix, this lane's block
+    // this chain's covmat_empirical (L = 64): entry (k, j) at Cl[16 k] for k < 16 (mj + 1)
+    double *const Cl = lds + Lay::STAGED + (CL ? cl * Lay::csize(d) + 128 * mj * (mj + 1) + (j & 15) : 0);
+    if constexpr (CL) {
+        for (int e = lane; e < Lay::csize(d); e += 64) lds[Lay::STAGED + cl * Lay::csize(d) + e] = 0.0;
+    }
     __syncthreads();
     const double *const Hs = lds + Lay::HS + j;   // H_jk at Hs[k * L]
-    const double *const R0c = lds + Lay::R0 + j;  // chol(covmat)_kj at R0c[k * L]
-    double *const stage = lds + Lay::TOTAL;       // [2][d][CPW] trace tile
+    const double *const R0c = (CL ? prm : lds) + Lay::R0 + j; // chol(covmat)_kj at R0c[k * L]
+    double *const stage = lds + Lay::STAGED + CPW * Lay::csize(d); // [2][d][CPW] trace tile
     const double tm = lds[Lay::TMEAN + j];
     const double min_var = lds[Lay::MINVAR], prodR0 = lds[Lay::PROD0];
 
-    double Rc[L], Cc[L];
+    double Rc[L], Cc[CL ? 1 : L];
 #pragma unroll
-    for (int k = 0; k < L; ++k) {
-        Rc[k] = R0c[k * L];
-        Cc[k] = 0.0;
-    }
+    for (int k = 0; k < L; ++k) Rc[k] = R0c[k * L];
+#pragma unroll
+    for (int k = 0; k < (CL ? 1 : L); ++k) Cc[k] = 0.0;
+    // one 16-row block B of this lane's column of covmat_empirical at a time (L = 64): f(k, reference to the entry)
+    auto c_block = [&](auto bc, auto &&f) {
+        constexpr int B = decltype(bc)::value;
+        if (B <= mj && mj < MB) { // the lanes whose column reaches into block B (rows 16 B .. 16 B + 15): whole 16-lane rows
+            double t[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t[k] = Cl[16 * (16 * B + k)];
+            f(t);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) Cl[16 * (16 * B + k)] = t[k];
+        }
+    };
     double theta = act ? (a.d_init ? a.d_init[(int64_t)j * n + cc] : lds[Lay::INIT + j]) : tm; // padding: v = theta - m = 0
     double mean = theta;
 
@@ -363,7 +454,12 @@ __global__ __launch_bounds__(256, L == 16 ? 3 : 2) void rwm_row_kernel(const Rwm
 #pragma unroll
         for (int k = 0; k < L; ++k) {
             if (act && k < d) { // column j of the symmetric covmat_empirical from its packed upper triangle; of R the part k <= j
-                Cc[k] = sp[(int64_t)(SL.C + (k <= j ? tri(k, j) : tri(j, k))) * n];
+                const double cv = sp[(int64_t)(SL.C + (k <= j ? tri(k, j) : tri(j, k))) * n];
+                if constexpr (CL) {
+                    if (k < 16 * (mj + 1)) Cl[16 * k] = cv;
+                } else {
+                    Cc[k] = cv;
+                }
                 Rc[k] = k <= j ? sp[(int64_t)(SL.R + tri(k, j)) * n] : 0.0;
             }
         }
@@ -427,27 +523,49 @@ __global__ __launch_bounds__(256, L == 16 ? 3 : 2) void rwm_row_kernel(const Rwm
         // operand comes from an active lane; the rows of chains that do not factor sit it out.
         if (refactor) {
             double (&Ac)[L] = Rc;
+            if constexpr (CL) {
 #pragma unroll
-            for (int k = 0; k < L; ++k) Ac[k] = Cc[k];
+                for (int k = 0; k < L; ++k) Ac[k] = ((k >> 4) <= mj && mj < MB) ? Cl[16 * k] : 0.0;
+            } else {
+#pragma unroll
+                for (int k = 0; k < L; ++k) Ac[k] = Cc[k];
+            }
             bool ok = true;
             double prod = 1.0;
+            int jo = j; // opaque: the 2 L lane masks j > p, j == p would otherwise be hoisted out of the iteration loop
+            asm volatile("" : "+v"(jo)); // into scalar registers and come back one v_readlane at a time
             row_unroll<0, L>([&](auto pc) {
                 constexpr int P = decltype(pc)::value;
                 if (P < d) { // uniform
-                    const RowVec<L> rowp(Ac[P]); // row p of the trailing matrix: entry j in lane j
-                    const double piv = rowp.template get<P>();
+                    double piv;
+                    if constexpr (CL) { // one chain per wavefront: the pivot is lane p's value, through a scalar register
+                        const uint64_t b = (uint64_t)__double_as_longlong(Ac[P]);
+                        const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)b, P), hi = __builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), P);
+                        piv = __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+                    } else {
+                        const RowVec<L> rowp(Ac[P]); // row p of the trailing matrix: entry j in lane j
+                        piv = rowp.template get<P>();
+                    }
                     ok = ok && (piv > 0.0);
                     double rjj, rinv;
                     fm_sqrt_rsq(piv, rjj, rinv);
                     prod *= rjj;
                     // finished row p of R: R_pj = a_pj / sqrt(a_pp) for j > p, the root itself at j = p, zero for j < p
-                    const double rp = (j > P) ? Ac[P] * rinv : (j == P ? rjj : 0.0);
+                    double rp;
+                    if constexpr (CL) {
+                        rp = (jo >= P) ? Ac[P] * rinv : 0.0; // lane p: a_pp / sqrt(a_pp), the root up to an ulp
+                    } else {
+                        rp = (jo > P) ? Ac[P] * rinv : (jo == P ? rjj : 0.0);
+                    }
                     if constexpr (P + 1 < L) {
                         // a_ij -= R_pi R_pj for the rows i > p (only the part i <= j is ever read), in groups of four
                         // rows.  The group that holds p also meets rows i < p, where R_pi = 0 and nothing changes, and
                         // row p itself, which is overwritten with the finished row right after.
                         const RowVec<L> rv(-rp);
-                        rv.template rows_from<P + 1>(Ac, rp);
+                        if constexpr (CL)
+                            rv.template rows_from<P + 1>(Ac, rp, d);
+                        else
+                            rv.template rows_from<P + 1>(Ac, rp);
                     }
                     Ac[P] = rp;
                 }
@@ -509,7 +627,7 @@ __global__ __launch_bounds__(256, L == 16 ? 3 : 2) void rwm_row_kernel(const Rwm
         double yr = 0.0;
         row_unroll<0, L / 8>([&](auto gc) {
             constexpr int G = decltype(gc)::value;
-            yv.template dot8<G>(yr, Rc + 8 * G);
+            yv.template dot8<G>(yr, Rc + 8 * G); // blocks past d multiply zeros: skipping them (uniform branches) measured slower
         });
         const double prop = theta + s_eff * yr;
         const double q = row_sum<L>(Y * Y);
@@ -542,7 +660,7 @@ __global__ __launch_bounds__(256, L == 16 ? 3 : 2) void rwm_row_kernel(const Rwm
                 if (act) tile[j * CPW + cl] = theta;
                 lds_barrier();
                 double *const row = a.d_trace + t_kept * d * n + c0;
-                for (int e = tid; e < d * CPW; e += 256) {
+                for (int e = tid; e < d * CPW; e += NTHR) {
                     const int k = e / CPW, q2 = e - k * CPW;
                     if (c0 + q2 < n) row[(int64_t)k * n + q2] = tile[e];
                 }
@@ -571,9 +689,19 @@ __global__ __launch_bounds__(256, L == 16 ? 3 : 2) void rwm_row_kernel(const Rwm
             const double res = act ? theta - mean : 0.0;
             mean += res * inv_i;
             const RowVec<L> bv((sfac * inv_i) * res);
+            if constexpr (CL) {
+                row_unroll<0, 4>([&](auto bc) {
+                    c_block(bc, [&](double(&t)[16]) {
 #pragma unroll
-            for (int k = 0; k < L; ++k) Cc[k] *= sfac;
-            bv.rows(Cc, res);
+                        for (int k = 0; k < 16; ++k) t[k] *= sfac;
+                        bv.template rows16<decltype(bc)::value>(t, res);
+                    });
+                });
+            } else {
+#pragma unroll
+                for (int k = 0; k < L; ++k) Cc[k] *= sfac;
+                bv.rows(Cc, res);
+            }
         }
     }
 
@@ -585,8 +713,9 @@ __global__ __launch_bounds__(256, L == 16 ? 3 : 2) void rwm_row_kernel(const Rwm
 #pragma unroll
             for (int k = 0; k < L; ++k) {
                 if (k <= j) {
-                    a.d_final_cov[(int64_t)(j * d + k) * n + c] = Cc[k];
-                    a.d_final_cov[(int64_t)(k * d + j) * n + c] = Cc[k];
+                    const double cv = CL ? Cl[16 * k] : Cc[CL ? 0 : k];
+                    a.d_final_cov[(int64_t)(j * d + k) * n + c] = cv;
+                    a.d_final_cov[(int64_t)(k * d + j) * n + c] = cv;
                 }
             }
         }
@@ -604,7 +733,7 @@ __global__ __launch_bounds__(256, L == 16 ? 3 : 2) void rwm_row_kernel(const Rwm
 #pragma unroll
             for (int k = 0; k < L; ++k) {
                 if (k <= j) {
-                    sp[(int64_t)(SL.C + tri(k, j)) * n] = Cc[k];
+                    sp[(int64_t)(SL.C + tri(k, j)) * n] = CL ? Cl[16 * k] : Cc[CL ? 0 : k];
                     sp[(int64_t)(SL.R + tri(k, j)) * n] = Rc[k];
                 }
             }
@@ -670,13 +799,21 @@ static int launch_rwm_row_l(const RwmArgs &a, const RwmParams &p, hipStream_t s)
     hipError_t e = hipMemcpyAsync(d_prm, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s); // blob is a local: do not let the copy outlive it
     if (e == hipSuccess) {
-        const size_t ldsb = (size_t)Lay::lds_doubles(d) * sizeof(double);
-        const unsigned grid = (unsigned)((a.n_chains + Lay::CPW - 1) / Lay::CPW);
-        if (a.d_state_in || a.d_state_out)
-            hipLaunchKernelGGL((rwm_row_kernel<L, true>), dim3(grid), dim3(256), ldsb, s, a, (const double *)d_prm);
-        else
-            hipLaunchKernelGGL((rwm_row_kernel<L, false>), dim3(grid), dim3(256), ldsb, s, a, (const double *)d_prm);
-        e = hipGetLastError();
+        // L = 64: as many chains (wavefronts) per workgroup as one CU's 160 KB of LDS holds, eight at most
+        int cpw = Lay::CPW;
+        if (L == 64) {
+            cpw = 8;
+            while (cpw > 1 && (size_t)Lay::lds_doubles(d, cpw) * sizeof(double) > 160 * 1024 - 512) --cpw;
+        }
+        const size_t ldsb = (size_t)Lay::lds_doubles(d, cpw) * sizeof(double);
+        const unsigned grid = (unsigned)((a.n_chains + cpw - 1) / cpw), block = L == 64 ? 64u * cpw : 256u;
+        auto go = [&](auto kern) {
+            hipError_t e0 = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+            if (e0 != hipSuccess) return e0;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(block), ldsb, s, a, (const double *)d_prm);
+            return hipGetLastError();
+        };
+        e = (a.d_state_in || a.d_state_out) ? go(rwm_row_kernel<L, true>) : go(rwm_row_kernel<L, false>);
     }
     hipError_t e2 = hipFreeAsync(d_prm, s);
     if (e != hipSuccess) return set_error(MCMC_E_HIP, "rwm_row_kernel launch failed: %s", hipGetErrorString(e));
@@ -689,7 +826,7 @@ int launch_rwm_row(const RwmArgs &a, const RwmParams &p, hipStream_t s)
     if (!rwm_row_serves(a, p.target_kind))
         return set_error(MCMC_E_UNSUPPORTED, "row kernel: Gaussian target, Philox streams, no per-iteration diagnostics, d <= %d", kMaxRowDimRwm);
     if ((int)p.tparams.size() != a.d + a.d * a.d) return set_error(MCMC_E_BAD_ARG, "gaussian target needs d + d*d parameters");
-    return a.d <= 16 ? launch_rwm_row_l<16>(a, p, s) : launch_rwm_row_l<32>(a, p, s);
+    return a.d <= 16 ? launch_rwm_row_l<16>(a, p, s) : (a.d <= 32 ? launch_rwm_row_l<32>(a, p, s) : launch_rwm_row_l<64>(a, p, s));
 }
 
 } // namespace mcmc

@@ -557,14 +557,15 @@ def test_paired_wave_kernel_targets_thinning_and_failure(cuda, oracle):
 
 @pytest.mark.parametrize("d,n,ass,ashs,w,win", [(11, 700, 20, 150, 0.0, 0), (13, 600, 0, 120, 0.0, 0), (16, 700, 25, 160, 0.05, 0),
                                                 (24, 600, 0, 150, 0.0, 40), (32, 700, 0, 180, 0.0, 0), (17, 500, 15, 0, 0.0, 0),
-                                                (5, 500, 20, 60, 0.0, 0)])
+                                                (5, 500, 20, 60, 0.0, 0), (33, 600, 20, 120, 0.0, 0), (48, 700, 0, 170, 0.0, 0),
+                                                (63, 800, 25, 200, 0.05, 0), (64, 700, 0, 190, 0.0, 70)])
 def test_row_kernel_matches_oracle_and_block_kernel(cuda, oracle, d, n, ass, ashs, w, win):
-    """One chain per row of 16 / 32 lanes (rwm_row.hip; what AUTO runs for 12 < d <= 32): a Philox run replayed through
+    """One chain per row of 16 / 32 / 64 lanes (rwm_row.hip; what AUTO runs for 12 < d <= 64): a Philox run replayed through
     the oracle with the streams mcmc_rwm_streams reports -- size phase, shape phase (in-register Cholesky every
     iteration), the three rate modes -- and against the per-workgroup kernel on the same run."""
     import mcmc_amd
 
-    nc = 37  # not a multiple of the 16 / 8 chains of a workgroup: the last one has shadow rows
+    nc = 37  # not a multiple of the 16 / 8 / 6 chains of a workgroup: the last one has shadow rows
     rng = np.random.default_rng(2000 + d)
     A = rng.standard_normal((d, d))
     Sig = A @ A.T / d + np.eye(d)
@@ -580,7 +581,7 @@ def test_row_kernel_matches_oracle_and_block_kernel(cuda, oracle, d, n, ass, ash
     assert np.all(row["status"].cpu().numpy() == 0)
     if d > 12:
         auto = mcmc_amd.adapt_rwm_batch(tgt, nc, init, cov0, n, ass, w, win, ashs, **kw)
-        assert cuda.equal(auto["theta_trace"], row["theta_trace"])  # AUTO picks this kernel for 12 < d <= 32
+        assert cuda.equal(auto["theta_trace"], row["theta_trace"])  # AUTO picks this kernel for 12 < d <= 64
     other = mcmc_amd.adapt_rwm_batch(tgt, nc, init, cov0, n, ass, w, win, ashs, kernel="block" if d > 12 else "lane", **kw)
     tr, to = row["theta_trace"].cpu().numpy(), other["theta_trace"].cpu().numpy()
     assert _rel(tr, to) < BLOCK_RTOL, _rel(tr, to)
@@ -603,7 +604,7 @@ def test_row_kernel_matches_oracle_and_block_kernel(cuda, oracle, d, n, ass, ash
 def test_row_kernel_sharding_thinning_resume_and_failure(cuda):
     import mcmc_amd
 
-    for d in (16, 29):
+    for d in (16, 29, 40, 64):
         Sig, H = _gauss(d, 0.7)
         tgt = mcmc_amd.Target.gaussian(np.zeros(d), H)
         cov0 = (1.0 / d) * np.eye(d)
@@ -637,7 +638,7 @@ def test_row_kernel_sharding_thinning_resume_and_failure(cuda):
     with pytest.raises(mcmc_amd.McmcError):
         mcmc_amd.adapt_rwm_batch(tgt, 4, np.zeros(d), cov0, 10, diagnostics=True, kernel="row")  # refused, not rerouted
     with pytest.raises(mcmc_amd.McmcError):
-        mcmc_amd.adapt_rwm_batch(mcmc_amd.Target.gaussian(np.zeros(40), np.eye(40)), 4, np.zeros(40), np.eye(40), 10, kernel="row")
+        mcmc_amd.adapt_rwm_batch(mcmc_amd.Target.gaussian(np.zeros(70), np.eye(70)), 4, np.zeros(70), np.eye(70), 10, kernel="row")
 
 
 def test_run_chains_gives_the_list_of_chains_melt_trace_expects(cuda, oracle):

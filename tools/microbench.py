@@ -266,6 +266,7 @@ if __name__ == "__main__" and "mid" in sys.argv:  # the 12 < d < 64 range (VERDI
                 kern = "row"
             rwm_block(d, 65536 if kern != "block" else 16384, 300, kernel=kern)
             rwm_block_shape(d, 65536 if kern != "block" else 8192, 600, kernel=kern)
-    for d in (48, 63):
-        rwm_block(d, 16384, 300)
-        rwm_block_shape(d, 8192, 600)
+    for d in (33, 48, 63, 64):  # one chain per wavefront (row kernel, L = 64) against the per-workgroup kernel
+        for kern in ("auto", "block"):
+            rwm_block(d, 32768 if kern != "block" else 16384, 300, kernel=kern)
+            rwm_block_shape(d, 32768 if kern != "block" else 8192, 600, kernel=kern)
