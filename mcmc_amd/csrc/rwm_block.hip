@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
     const int d = a.d;
     const BlockLayout L(d);
     const int T = L.T;
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x; // not const: made opaque once per iteration (see the top of the loop)
     double *const A = lds;        // packed upper factor R, (r,c) r<=c at c(c+1)/2 + r
     double *const th = A + T;     // theta_current
     double *const mn = th + d;    // theta_mean
@@ -161,8 +161,10 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
     // Hq rows in LDS for NT = 3 .. 6 (below: the row kernel serves production and the runs are two loads long): the 256 registers of the NT = 7, 8 kernels are full, and the extra loop spills
     // (d = 100: 4.80 ms against 4.21 per 100 iterations of 4 096 chains, measured)
     const int TP = __builtin_amdgcn_readfirstlane((int)prm[L.meta()]), KL = (NT >= 3 && NT <= 6) ? __builtin_amdgcn_readfirstlane((int)prm[L.meta() + 1]) : 0;
-    const int t_row = (int)prm[L.ttab() + 2 * tid], t_first = (int)prm[L.ttab() + 2 * tid + 1];
-    const int p_col = (int)prm[L.ptab() + 3 * tid], p_first = (int)prm[L.ptab() + 3 * tid + 1], p_len = (int)prm[L.ptab() + 3 * tid + 2];
+    int t_row = (int)prm[L.ttab() + 2 * tid];
+    const int t_first = (int)prm[L.ttab() + 2 * tid + 1];
+    int p_col = (int)prm[L.ptab() + 3 * tid];
+    const int p_first = (int)prm[L.ptab() + 3 * tid + 1], p_len = (int)prm[L.ptab() + 3 * tid + 2];
     const int r_first = tid < d ? (int)prm[L.pred() + 2 * tid] : 0, r_count = tid < d ? (int)prm[L.pred() + 2 * tid + 1] : 0;
     const int ti = tid >> 4, tk = tid & 15; // tile row / column: the 16 owners of a row sit in one wave
 
@@ -372,6 +374,12 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
         const int li = i - i0; // position inside this launch: streams, diagnostics and the cooling table are per launch
         const double di = (double)i;
         const double cool = cool_next;
+        // The lane masks of this loop (tid < d, tid == 0, first lane of a wave, "has a run") are loop invariants: left
+        // alone the compiler computes ~30 of them once, keeps them in scalar registers it does not have, and fetches
+        // each back with two v_readlane per use.  Opaque values make it form a mask where it is used (one v_cmp).
+        // Only where registers are short (NT >= 7: 44 bytes of scratch gone, d = 100 +4 %); at NT = 5, 6 the recomputed
+        // masks and addresses cost 5 % (measured).
+        if constexpr (NT >= 7) asm volatile("" : "+v"(tid), "+v"(t_row), "+v"(p_col));
         if (ass != 0 && li < a.n_iterations) cool_next = a.d_cool_pow[li + 1];
         // ---- adaptation of covmat_proposal (adaptMCMC_source.cpp:117-139), replicated ---------------
         bool rescale = false, refactor = false;
