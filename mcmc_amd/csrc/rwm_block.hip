@@ -158,9 +158,11 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
     const double *__restrict__ Hd = prm + L.hdiag();
     const double *__restrict__ Hq = prm + L.hq();
     // this thread's runs of the target's and the proposal's triangular sums
-    // Hq rows in LDS for NT = 3 .. 6 (below: the row kernel serves production and the runs are two loads long): the 256 registers of the NT = 7, 8 kernels are full, and the extra loop spills
-    // (d = 100: 4.80 ms against 4.21 per 100 iterations of 4 096 chains, measured)
-    const int TP = __builtin_amdgcn_readfirstlane((int)prm[L.meta()]), KL = (NT >= 3 && NT <= 6) ? __builtin_amdgcn_readfirstlane((int)prm[L.meta() + 1]) : 0;
+    // Hq rows in LDS for NT = 3 .. 7 (below: the row kernel serves production and the runs are two loads long; NT = 8:
+    // the chain's own state leaves no room).  At NT = 7 this only pays since the lane masks are no longer hoisted
+    // (see the top of the iteration loop): before, the extra loop spilled and d = 100 ran 4.80 ms instead of 4.21
+    // per 100 iterations of 4 096 chains; now 3.33 against 3.54 (size phase without size adaptation, measured).
+    const int TP = __builtin_amdgcn_readfirstlane((int)prm[L.meta()]), KL = (NT >= 3 && NT <= 7) ? __builtin_amdgcn_readfirstlane((int)prm[L.meta() + 1]) : 0;
     int t_row = (int)prm[L.ttab() + 2 * tid];
     const int t_first = (int)prm[L.ttab() + 2 * tid + 1];
     int p_col = (int)prm[L.ptab() + 3 * tid];
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             // Coefficients KL .. KL + CH - 1 are requested from L2 first and used last; the rows before them sit in LDS
             // (the L2 round trips of this sum, TP / CH of them, were 19 % of an iteration at d = 100; measured)
             int t_l2 = 0;
-            if constexpr (NT >= 3 && NT <= 6) {
+            if constexpr (NT >= 3 && NT <= 7) {
                 double hl[CH];
 #pragma unroll
                 for (int u = 0; u < CH; ++u) hl[u] = (KL + u < TP) ? hp[(KL + u) * kBlockThreads] : 0.0;
@@ -790,7 +792,7 @@ int launch_rwm_block_with(const RwmArgs &a, const RwmParams &p, hipStream_t s, b
     // rows of Hq in LDS: what is left of a CU's 160 KB beside the state of the chains it holds (launch bounds: 4 / 3 / 2)
     const int nt_ = (d + 15) / 16, per_cu = nt_ <= 2 ? 4 : (nt_ <= 4 ? 3 : 2);
     const long free_doubles = (160 * 1024 / per_cu - 1024) / 8 - L.lds_doubles();
-    const int KL = (user || nt_ < 3 || nt_ > 6) ? 0 : (int)std::max(0L, std::min<long>(TP, free_doubles / kBlockThreads)) & ~3;
+    const int KL = (user || nt_ < 3 || nt_ > 7) ? 0 : (int)std::max(0L, std::min<long>(TP, free_doubles / kBlockThreads)) & ~3;
     blob[L.meta() + 1] = KL;
     for (int tid = 0; tid < kBlockThreads; ++tid) {
         const bool ht = tid < (int)tseg.row.size(), hp = tid < (int)pseg.row.size();
