@@ -611,16 +611,25 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 3 : (L == 32 ? 2 : 1
         }
 
         // ---- draws: this lane's normal, the chain's uniform (:149-152,174) ----------------------------------
-        double z0, z1, u0, u1, logA;
+        // ONE Philox block per lane: the even lane 2 b draws block b (normals 2 b, 2 b + 1) and hands the second normal
+        // to its odd neighbour, which leaves the odd lanes free -- lane 1 of every 16-lane row draws the uniform's block
+        // with the same instructions (log u0 is Box-Muller's first step) and its row reads log A from it.
+        double Y, logA;
         {
             PhiloxKey kk = key; // opaque copy: the ten round keys are formed by scalar adds here, not hoisted and spilled
             asm volatile("" : "+s"(kk.k0), "+s"(kk.k1));
             const ScalarCoef<16> tl = fm_tab<16>(FT_LOG, i), ts = fm_tab<16>(FT_SINCOS, i);
-            philox_normal2_t(kk, gchain, (uint32_t)i, TAG_RWM_NORMAL, (uint32_t)(j >> 1), z0, z1, tl, ts);
-            philox_uniform2(kk, gchain, (uint32_t)i, TAG_RWM_UNIFORM, 0u, u0, u1);
-            logA = fm_log_t(u0, tl); // A is in the open interval (0,1)
+            const bool uni = (j & 15) == 1;
+            double z0, z1, lg;
+            philox_normal2_log_t(kk, gchain, (uint32_t)i, uni ? TAG_RWM_UNIFORM : TAG_RWM_NORMAL, uni ? 0u : (uint32_t)(j >> 1), z0, z1, lg,
+                                 tl, ts);
+            const uint64_t zb = (uint64_t)__double_as_longlong(z1); // quad_perm [0,0,2,2]: the even neighbour's second normal
+            const uint32_t zl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)zb, 0xA0, 0xf, 0xf, false);
+            const uint32_t zh = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(zb >> 32), 0xA0, 0xf, 0xf, false);
+            const double zodd = __longlong_as_double((long long)(((uint64_t)zh << 32) | zl));
+            Y = act ? ((j & 1) ? zodd : z0) : 0.0;
+            logA = row_bcast<1>(lg); // A is in the open interval (0,1)
         }
-        const double Y = act ? ((j & 1) ? z1 : z0) : 0.0;
 
         // ---- proposal theta + s (Y R) (:153-154) and |Y|^2 for the Hastings term --------------------------------
         const RowVec<L> yv(Y);
