@@ -493,12 +493,43 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 3 : (L == 32 ? 2 : 1
     for (int i = i0 + 1; i <= i0 + a.n_iterations; ++i) {
         const int li = i - i0; // position inside this launch (cooling table)
         const double di = (double)i;
+        // ---- draws: this lane's normal, the chain's uniform (:149-152,174) ----------------------------------
+        // ONE Philox block per lane: the even lane 2 b draws block b (normals 2 b, 2 b + 1) and hands the second normal
+        // to its odd neighbour, which leaves the odd lanes free -- lane 1 of every 16-lane row draws the uniform's block
+        // with the same instructions (log u0 is Box-Muller's first step) and its row reads log A from it.
+        double Y, logA;
+        {
+            PhiloxKey kk = key; // opaque copy: the ten round keys are formed by scalar adds here, not hoisted and spilled
+            asm volatile("" : "+s"(kk.k0), "+s"(kk.k1));
+            const ScalarCoef<16> tl = fm_tab<16>(FT_LOG, i), ts = fm_tab<16>(FT_SINCOS, i);
+            const bool uni = (j & 15) == 1;
+            double z0, z1, lg;
+            philox_normal2_log_t(kk, gchain, (uint32_t)i, uni ? TAG_RWM_UNIFORM : TAG_RWM_NORMAL, uni ? 0u : (uint32_t)(j >> 1), z0, z1, lg,
+                                 tl, ts);
+            const uint64_t zb = (uint64_t)__double_as_longlong(z1); // quad_perm [0,0,2,2]: the even neighbour's second normal
+            const uint32_t zl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)zb, 0xA0, 0xf, 0xf, false);
+            const uint32_t zh = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(zb >> 32), 0xA0, 0xf, 0xf, false);
+            const double zodd = __longlong_as_double((long long)(((uint64_t)zh << 32) | zl));
+            Y = act ? ((j & 1) ? zodd : z0) : 0.0;
+            logA = row_bcast<1>(lg); // A is in the open interval (0,1)
+        }
+
+        const double q = row_sum<L>(Y * Y); // |Y|^2 for the Hastings term
+        // The two exponentials of an iteration -- the size adaptation's multiplier and the Hastings term's exp(-q / 2) --
+        // in ONE evaluation: odd lanes take the first argument, even lanes the second, lanes 1 and 0 of the row report.
+        double e_adapt, e_hast;
+        {
+            const double xa = (ass != 0 ? a.d_cool_pow[li] : 0.0) * (rate - 0.234);
+            const double ex = fm_exp_t((j & 1) ? xa : -0.5 * q, fm_tab<16>(FT_EXP, i));
+            e_adapt = row_bcast<1>(ex);
+            e_hast = row_bcast<0>(ex);
+        }
         // ---- adaptation of covmat_proposal (adaptMCMC_source.cpp:117-139), replicated ------------------
         bool rescale = false, refactor = false;
         if (ass != 0 && i >= ass && (ashs == 0 || mul_rn(rate, di) < (double)ashs)) {
             // polynomial coefficients arrive by one scalar load per use (fastmath.h: fm_tab) instead of living in -- and
             // spilling from -- scalar registers across the loop; same operations, same bits as fm_exp / fm_log
-            const double scaling_multiplier = fm_exp_t(a.d_cool_pow[li] * (rate - 0.234), fm_tab<16>(FT_EXP, i));
+            const double scaling_multiplier = e_adapt;
             scaling_sd = mul_rn(scaling_sd, scaling_multiplier);
             scaling_sd = (a.max_scaling_sd < scaling_sd) ? a.max_scaling_sd : scaling_sd;
             const double s2 = mul_rn(scaling_sd, scaling_sd);
@@ -610,27 +641,6 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 3 : (L == 32 ? 2 : 1
             fm_sqrt_rsq(a.twopi_pow_d * det, sq_unused, rootTerm);
         }
 
-        // ---- draws: this lane's normal, the chain's uniform (:149-152,174) ----------------------------------
-        // ONE Philox block per lane: the even lane 2 b draws block b (normals 2 b, 2 b + 1) and hands the second normal
-        // to its odd neighbour, which leaves the odd lanes free -- lane 1 of every 16-lane row draws the uniform's block
-        // with the same instructions (log u0 is Box-Muller's first step) and its row reads log A from it.
-        double Y, logA;
-        {
-            PhiloxKey kk = key; // opaque copy: the ten round keys are formed by scalar adds here, not hoisted and spilled
-            asm volatile("" : "+s"(kk.k0), "+s"(kk.k1));
-            const ScalarCoef<16> tl = fm_tab<16>(FT_LOG, i), ts = fm_tab<16>(FT_SINCOS, i);
-            const bool uni = (j & 15) == 1;
-            double z0, z1, lg;
-            philox_normal2_log_t(kk, gchain, (uint32_t)i, uni ? TAG_RWM_UNIFORM : TAG_RWM_NORMAL, uni ? 0u : (uint32_t)(j >> 1), z0, z1, lg,
-                                 tl, ts);
-            const uint64_t zb = (uint64_t)__double_as_longlong(z1); // quad_perm [0,0,2,2]: the even neighbour's second normal
-            const uint32_t zl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)zb, 0xA0, 0xf, 0xf, false);
-            const uint32_t zh = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(zb >> 32), 0xA0, 0xf, 0xf, false);
-            const double zodd = __longlong_as_double((long long)(((uint64_t)zh << 32) | zl));
-            Y = act ? ((j & 1) ? zodd : z0) : 0.0;
-            logA = row_bcast<1>(lg); // A is in the open interval (0,1)
-        }
-
         // ---- proposal theta + s (Y R) (:153-154) and |Y|^2 for the Hastings term --------------------------------
         const RowVec<L> yv(Y);
         double yr = 0.0;
@@ -639,7 +649,6 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 3 : (L == 32 ? 2 : 1
             yv.template dot8<G>(yr, Rc + 8 * G); // blocks past d multiply zeros: skipping them (uniform branches) measured slower
         });
         const double prop = theta + s_eff * yr;
-        const double q = row_sum<L>(Y * Y);
 
         // ---- target and Metropolis-Hastings log ratio (:157-171) ------------------------------------------------
         const double t_prop = target(prop);
@@ -648,7 +657,7 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 3 : (L == 32 ? 2 : 1
             la = -__builtin_inf();
         } else {
             la = t_prop - t_cur;
-            const double pe = rootTerm * fm_exp_t(-0.5 * q, fm_tab<16>(FT_EXP, li));
+            const double pe = rootTerm * e_hast;
             double p = fm_log_t(pe, fm_tab<16>(FT_LOG, li));
             p = (pe == 0.0) ? -__builtin_inf() : p; // the special cases of fm_log<true>: the NaN-reject path needs them
             p = (pe < 0.0 || pe != pe) ? __builtin_nan("") : p;
