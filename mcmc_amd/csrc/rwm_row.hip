@@ -359,7 +359,7 @@ struct RowLayout {
 };
 
 template <int L, bool STATE>
-__global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 3 : (L == 32 ? 2 : 1)) void rwm_row_kernel(const RwmArgs a, const double *__restrict__ prm)
+__global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 4 : (L == 32 ? 2 : 1)) void rwm_row_kernel(const RwmArgs a, const double *__restrict__ prm)
 {
     using Lay = RowLayout<L>;
     constexpr int RPW = 64 / L;
