@@ -276,7 +276,7 @@ def main():
         return float(t.item())
 
     wl = args.workload
-    defaults = {"c2": (65536, 10000, 5, 1), "c3": (1 << 20, 2000, 3, 1), "c4": (131072, 5000, 1, 0),
+    defaults = {"c2": (65536, 10000, 20, 3), "c3": (1 << 20, 2000, 5, 2), "c4": (131072, 5000, 1, 0),
                 "c4s": (131072, 5000, 1, 0), "c5": (1 << 20, 200, 2, 1)}
     n_chains = args.chains or defaults[wl][0]
     n_iter = args.iters or defaults[wl][1]
