@@ -18,11 +18,15 @@
  *   - Every call returns MCMC_OK (0) or a negative MCMC_E_* code; mcmc_amd_last_error()
  *     gives the message.  Per-chain failures (what would be a C++ exception inside the
  *     reference's loop) are reported through the d_status / status outputs instead.
- *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  A batch call
- *     uploads its small shared parameter block on that stream and waits for that copy (the
- *     host staging buffer is a local), then launches and returns while the kernel runs: the
- *     sampling itself is asynchronous on `stream`, work queued on it earlier is waited for.
- *     The single-chain calls synchronise before returning.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  A batch call is
+ *     asynchronous on `stream`: its small shared parameter block (and the cooling table)
+ *     travels in the arguments of a few fill kernels queued ahead of the sampling kernel, so
+ *     the call returns at once and waits for nothing queued on the stream earlier.  It does
+ *     wait once (a copy + a stream synchronisation) where such a block exceeds 224 KB -- a
+ *     user target's data set, the cooling table of a call of more than 28 671 iterations --
+ *     and when a run is resumed under MCMC_KERNEL_AUTO (the checkpoint's kernel tag is read
+ *     back).  The single-chain calls and the density / walker helpers synchronise before
+ *     returning.
  *   - Random numbers: rng_mode MCMC_RNG_PHILOX draws from Philox4x32-10 keyed by `seed` and
  *     counted by (global chain id, iteration, draw), so results do not depend on how chains
  *     are split over launches or GPUs; MCMC_RNG_INJECTED consumes caller-supplied N(0,1) /

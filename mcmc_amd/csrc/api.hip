@@ -221,9 +221,8 @@ extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_co
         for (int i = 0; i <= cfg->n_iterations; ++i)
             cool[i] = std::pow(cfg->adapt_size_cooling, cfg->iter_offset + i - cfg->adapt_size_start);
         hipError_t e = hipMallocAsync((void **)&d_cool, cool.size() * sizeof(double), s);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_cool, cool.data(), cool.size() * sizeof(double), hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s); // `cool` is a local: do not let the copy outlive it
-        if (e != hipSuccess) return release(set_error(MCMC_E_HIP, "cooling table upload failed: %s", hipGetErrorString(e)));
+        if (e != hipSuccess) return release(set_error(MCMC_E_HIP, "cooling table allocation failed: %s", hipGetErrorString(e)));
+        if (const int ru = upload_block(d_cool, cool.data(), cool.size(), s); ru != MCMC_OK) return release(ru);
         a.d_cool_pow = d_cool;
     }
     a.win_words = cfg->acceptance_rate_weight == 0 ? accept_window_words(cfg->acceptance_window) : 0;

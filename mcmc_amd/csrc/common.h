@@ -142,6 +142,8 @@ int launch_rwm_lane(const RwmArgs &a, const RwmParams &p, hipStream_t s);
 int launch_rwm_block(const RwmArgs &a, const RwmParams &p, hipStream_t s);
 bool rwm_pair_serves(const RwmArgs &a);
 bool rwm_row_serves(const RwmArgs &a, int target_kind);
+// host doubles -> device, ordered on the stream without waiting for it (kernel-argument fills; gibbs.hip)
+int upload_block(double *d_dst, const double *h_src, size_t count, hipStream_t s);
 int launch_rwm_row(const RwmArgs &a, const RwmParams &p, hipStream_t s);
 int launch_rwm_pair(const RwmArgs &a, const RwmParams &p, hipStream_t s);
 int launch_rwm_streams(uint64_t seed, int64_t chain_offset, int64_t n_chains, int32_t n_iterations,

@@ -490,6 +490,40 @@ static int launch_gibbs_on_block(const GibbsArgs &a, bool tail_safe, const doubl
     return moments ? go(gibbs_kernel<false, true>) : go(gibbs_kernel<false, false>);
 }
 
+// Host doubles -> device memory, ordered on `s`, WITHOUT waiting for the stream: the data travels in the ARGUMENTS of
+// small fill kernels (copied when the launch is made), so the host buffer may be a local of the caller and nothing
+// queued on the stream earlier is waited for.  Above kUploadByArgs doubles (64 launches): one copy and one wait.
+constexpr int kFillChunk = 448; // 3 584 B of kernel arguments per fill launch
+constexpr size_t kUploadByArgs = 64 * (size_t)kFillChunk;
+struct FillChunk {
+    double v[kFillChunk];
+};
+__global__ __launch_bounds__(kFillChunk) void scratch_fill_kernel(double *__restrict__ dst, int count, const FillChunk c)
+{
+    const int t = threadIdx.x;
+    if (t < count) dst[t] = c.v[t];
+}
+int upload_block(double *d_dst, const double *h_src, size_t count, hipStream_t s)
+{
+    static_assert(sizeof(FillChunk) + 16 <= 4096, "fill arguments must stay inside 4 KB");
+    if (count > kUploadByArgs) {
+        hipError_t e = hipMemcpyAsync(d_dst, h_src, count * sizeof(double), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s); // the host buffer may not outlive the call
+        if (e != hipSuccess) return set_error(MCMC_E_HIP, "parameter upload failed: %s", hipGetErrorString(e));
+        return MCMC_OK;
+    }
+    for (size_t off = 0; off < count; off += kFillChunk) {
+        const int cnt = (int)(count - off < (size_t)kFillChunk ? count - off : (size_t)kFillChunk);
+        FillChunk c;
+        for (int t = 0; t < cnt; ++t) c.v[t] = h_src[off + t];
+        for (int t = cnt; t < kFillChunk; ++t) c.v[t] = 0.0;
+        hipLaunchKernelGGL(scratch_fill_kernel, dim3(1), dim3(kFillChunk), 0, s, d_dst + off, cnt, c);
+        const hipError_t el = hipGetLastError();
+        if (el != hipSuccess) return set_error(MCMC_E_HIP, "scratch_fill_kernel launch failed: %s", hipGetErrorString(el));
+    }
+    return MCMC_OK;
+}
+
 int launch_gibbs(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipStream_t s)
 {
     const int d = a.d;
@@ -498,13 +532,8 @@ int launch_gibbs(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipSt
     build_gibbs_block(p, blk.data());
     double *d_blk = nullptr;
     MCMC_HIP_CHECK(hipMallocAsync((void **)&d_blk, blk.size() * sizeof(double), s));
-    hipError_t ec = hipMemcpyAsync(d_blk, blk.data(), blk.size() * sizeof(double), hipMemcpyHostToDevice, s);
-    if (ec == hipSuccess) ec = hipStreamSynchronize(s); // blk is a local: do not let the copy outlive it
-    if (ec != hipSuccess) {
-        (void)hipFreeAsync(d_blk, s);
-        return set_error(MCMC_E_HIP, "gibbs: parameter upload failed: %s", hipGetErrorString(ec));
-    }
-    int rc = launch_gibbs_on_block(a, tail_safe, d_blk, s);
+    int rc = upload_block(d_blk, blk.data(), blk.size(), s);
+    if (rc == MCMC_OK) rc = launch_gibbs_on_block(a, tail_safe, d_blk, s);
     hipError_t e = hipFreeAsync(d_blk, s);
     if (rc == MCMC_OK && e != hipSuccess) rc = set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e));
     return rc;
@@ -518,18 +547,8 @@ int launch_gibbs(const GibbsArgs &a, const GibbsParams &p, bool tail_safe, hipSt
 // (kFillChunk doubles per launch): no host buffer has to outlive the call, nothing is allocated or synchronised, and
 // every launch is capturable.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU race.
 constexpr int kGibbsScratchDoubles = 20480; // 160 KB: the block of d = 128 is 17 280 doubles
-constexpr int kFillChunk = 448;             // 3 584 B of kernel arguments per fill launch
 constexpr int kMaxDevices = 16;
 static __device__ __align__(256) double g_gibbs_scratch[kGibbsScratchDoubles];
-
-struct FillChunk {
-    double v[kFillChunk];
-};
-__global__ __launch_bounds__(kFillChunk) void scratch_fill_kernel(double *__restrict__ dst, int count, const FillChunk c)
-{
-    const int t = threadIdx.x;
-    if (t < count) dst[t] = c.v[t];
-}
 
 // host staging of the block while it is cut into fill arguments: static like the device array (one per device, no
 // heap, no 160 KB stack frame), and like it shared by the calls on that device
@@ -578,7 +597,6 @@ int launch_gibbs_noalloc(const GibbsArgs &a, const GibbsParams &p, bool tail_saf
     int rc = gibbs_scratch_ptr(&ptr, &dev);
     if (rc != MCMC_OK) return rc;
     // the whole block of this call is written (padding included), so nothing of the previous call's contents is read
-    static_assert(sizeof(FillChunk) + 16 <= 4096, "fill arguments must stay inside 4 KB");
     double *const blk = g_gibbs_stage[dev];
     build_gibbs_block(p, blk);
     for (size_t off = 0; off < total; off += kFillChunk) {

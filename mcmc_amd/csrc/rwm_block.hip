@@ -814,8 +814,10 @@ int launch_rwm_block_with(const RwmArgs &a, const RwmParams &p, hipStream_t s, b
     }
     double *d_prm = nullptr;
     MCMC_HIP_CHECK(hipMallocAsync((void **)&d_prm, blob.size() * sizeof(double), s));
-    MCMC_HIP_CHECK(hipMemcpyAsync(d_prm, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    MCMC_HIP_CHECK(hipStreamSynchronize(s)); // blob is a local: do not let the copy outlive it
+    if (const int ru = upload_block(d_prm, blob.data(), blob.size(), s); ru != MCMC_OK) {
+        (void)hipFreeAsync(d_prm, s);
+        return ru;
+    }
     const size_t ldsb = ((size_t)L.lds_doubles() + (size_t)KL * kBlockThreads) * sizeof(double);
     const bool full = a.d_Z || a.d_sigma_trace || a.d_accepted || a.d_log_acceptance || a.d_log_A || a.d_scaling_sd ||
                       a.d_scaling_multiplier || a.d_rate_trace;

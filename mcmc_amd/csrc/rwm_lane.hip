@@ -414,8 +414,10 @@ int launch_rwm_lane_with(const RwmArgs &a, const RwmParams &p, hipStream_t s, co
     for (int e = 0; e < L.NP; ++e) blob[L.TPRM + e] = p.tparams[e];
     double *d_prm = nullptr;
     MCMC_HIP_CHECK(hipMallocAsync((void **)&d_prm, blob.size() * sizeof(double), s));
-    MCMC_HIP_CHECK(hipMemcpyAsync(d_prm, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    MCMC_HIP_CHECK(hipStreamSynchronize(s)); // blob is a local: do not let the copy outlive it
+    if (const int ru = upload_block(d_prm, blob.data(), blob.size(), s); ru != MCMC_OK) {
+        (void)hipFreeAsync(d_prm, s);
+        return ru;
+    }
     const int64_t grid = (a.n_chains + 63) / 64;
     const size_t ldsb = (size_t)L.LDS_DOUBLES * sizeof(double);
     const bool full = a.d_Z || a.d_sigma_trace || a.d_accepted || a.d_log_acceptance || a.d_log_A || a.d_scaling_sd ||

@@ -595,8 +595,10 @@ int launch_rwm_pair_with(const RwmArgs &a, const RwmParams &p, hipStream_t s, in
     blob[L.PROD0] = prod0;
     double *d_prm = nullptr;
     MCMC_HIP_CHECK(hipMallocAsync((void **)&d_prm, blob.size() * sizeof(double), s));
-    MCMC_HIP_CHECK(hipMemcpyAsync(d_prm, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    MCMC_HIP_CHECK(hipStreamSynchronize(s)); // blob is a local: do not let the copy outlive it
+    if (const int ru = upload_block(d_prm, blob.data(), blob.size(), s); ru != MCMC_OK) {
+        (void)hipFreeAsync(d_prm, s);
+        return ru;
+    }
     const int64_t grid = (a.n_chains + 64 * kPairGroups - 1) / (64 * kPairGroups);
     hipError_t e1 = launch(state ? 2 : (moments ? 1 : 0), (unsigned)grid, 128u * kPairGroups, (size_t)L.LDS_DOUBLES * sizeof(double), s, a, d_prm);
     hipError_t e2 = hipFreeAsync(d_prm, s);

@@ -814,9 +814,13 @@ static int launch_rwm_row_l(const RwmArgs &a, const RwmParams &p, hipStream_t s)
     blob[Lay::PROD0] = prod0;
     double *d_prm = nullptr;
     MCMC_HIP_CHECK(hipMallocAsync((void **)&d_prm, blob.size() * sizeof(double), s));
-    hipError_t e = hipMemcpyAsync(d_prm, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s); // blob is a local: do not let the copy outlive it
-    if (e == hipSuccess) {
+    hipError_t e = hipSuccess;
+    const int ru = upload_block(d_prm, blob.data(), blob.size(), s);
+    if (ru != MCMC_OK) {
+        (void)hipFreeAsync(d_prm, s);
+        return ru;
+    }
+    {
         // L = 64: as many chains (wavefronts) per workgroup as one CU's 160 KB of LDS holds, eight at most
         int cpw = Lay::CPW;
         if (L == 64) {
