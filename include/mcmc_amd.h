@@ -25,8 +25,9 @@
  *     wait once (a copy + a stream synchronisation) where such a block exceeds 224 KB -- a
  *     user target's data set, the cooling table of a call of more than 28 671 iterations --
  *     and when a run is resumed under MCMC_KERNEL_AUTO (the checkpoint's kernel tag is read
- *     back).  The single-chain calls and the density / walker helpers synchronise before
- *     returning.
+ *     back).  (The HIP runtime may still hold a launch on the host when kernels that use
+ *     scratch memory follow one another on a busy device.)  The single-chain calls and the
+ *     density / walker helpers synchronise before returning.
  *   - Random numbers: rng_mode MCMC_RNG_PHILOX draws from Philox4x32-10 keyed by `seed` and
  *     counted by (global chain id, iteration, draw), so results do not depend on how chains
  *     are split over launches or GPUs; MCMC_RNG_INJECTED consumes caller-supplied N(0,1) /

@@ -142,6 +142,9 @@ int launch_rwm_lane(const RwmArgs &a, const RwmParams &p, hipStream_t s);
 int launch_rwm_block(const RwmArgs &a, const RwmParams &p, hipStream_t s);
 bool rwm_pair_serves(const RwmArgs &a);
 bool rwm_row_serves(const RwmArgs &a, int target_kind);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel, device and size: the call waits for the device to go
+// idle when made while work is in flight (measured: 14 ms behind a 14 ms launch), so it must not precede every launch
+hipError_t ensure_dynamic_lds(const void *kern, size_t bytes);
 // host doubles -> device, ordered on the stream without waiting for it (kernel-argument fills; gibbs.hip)
 int upload_block(double *d_dst, const double *h_src, size_t count, hipStream_t s);
 int launch_rwm_row(const RwmArgs &a, const RwmParams &p, hipStream_t s);

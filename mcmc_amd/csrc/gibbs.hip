@@ -19,6 +19,10 @@
 //     512 contiguous bytes per wavefront.
 #include <mutex>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "common.h"
 #include "normal_cdf.h"
 #include "philox.h"
@@ -488,6 +492,21 @@ static int launch_gibbs_on_block(const GibbsArgs &a, bool tail_safe, const doubl
     };
     if (tail_safe) return moments ? go(gibbs_kernel<true, true>) : go(gibbs_kernel<true, false>);
     return moments ? go(gibbs_kernel<false, true>) : go(gibbs_kernel<false, false>);
+}
+
+hipError_t ensure_dynamic_lds(const void *kern, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, size_t> have; // (kernel, device) -> largest size set so far
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &h = have[{kern, dev}];
+    if (bytes <= h) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) h = bytes;
+    return e;
 }
 
 // Host doubles -> device memory, ordered on `s`, WITHOUT waiting for the stream: the data travels in the ARGUMENTS of

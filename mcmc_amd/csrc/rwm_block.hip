@@ -838,7 +838,7 @@ int launch_rwm_block(const RwmArgs &a, const RwmParams &p, hipStream_t s)
         a, p, s, false,
         [nt](int full, unsigned grid, unsigned block, size_t ldsb, hipStream_t st, const RwmArgs &aa, const double *d_prm) {
             auto go = [&](auto kern) {
-                hipError_t e0 = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+                hipError_t e0 = ensure_dynamic_lds((const void *)kern, ldsb);
                 if (e0 != hipSuccess) return e0;
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(block), ldsb, st, aa, d_prm);
                 return hipGetLastError();

@@ -830,7 +830,7 @@ static int launch_rwm_row_l(const RwmArgs &a, const RwmParams &p, hipStream_t s)
         const size_t ldsb = (size_t)Lay::lds_doubles(d, cpw) * sizeof(double);
         const unsigned grid = (unsigned)((a.n_chains + cpw - 1) / cpw), block = L == 64 ? 64u * cpw : 256u;
         auto go = [&](auto kern) {
-            hipError_t e0 = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+            hipError_t e0 = ensure_dynamic_lds((const void *)kern, ldsb);
             if (e0 != hipSuccess) return e0;
             hipLaunchKernelGGL(kern, dim3(grid), dim3(block), ldsb, s, a, (const double *)d_prm);
             return hipGetLastError();
