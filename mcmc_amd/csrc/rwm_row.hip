@@ -582,12 +582,8 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 4 : (L == 32 ? 2 : 1
                     fm_sqrt_rsq(piv, rjj, rinv);
                     prod *= rjj;
                     // finished row p of R: R_pj = a_pj / sqrt(a_pp) for j > p, the root itself at j = p, zero for j < p
-                    double rp;
-                    if constexpr (CL) {
-                        rp = (jo >= P) ? Ac[P] * rinv : 0.0; // lane p: a_pp / sqrt(a_pp), the root up to an ulp
-                    } else {
-                        rp = (jo > P) ? Ac[P] * rinv : (jo == P ? rjj : 0.0);
-                    }
+                    // (lane p: a_pp / sqrt(a_pp), the root up to an ulp -- one lane mask instead of two)
+                    const double rp = (jo >= P) ? Ac[P] * rinv : 0.0;
                     if constexpr (P + 1 < L) {
                         // a_ij -= R_pi R_pj for the rows i > p (only the part i <= j is ever read), in groups of four
                         // rows.  The group that holds p also meets rows i < p, where R_pi = 0 and nothing changes, and
