@@ -408,12 +408,31 @@ def main():
         with np.errstate(all="ignore"):
             extra["rhat_max"] = _finite(np.max(rh))  # null when the within-chain variance is 0 (all chains frozen)
         if not args.no_ess:
-            sub = res[trace_key][:, :, : min(1024, n_chains)].contiguous()
-            ess = diag.chain_ess(sub, burn, min(500, (n_kept - burn) // 2))
+            n_s = min(1024, n_chains)
+            sub = res[trace_key][:, :, :n_s].contiguous()
+            # Geyer's sum is cut at max_lag; a chain whose sum was still positive there has its ESS OVER-stated
+            # (tests/test_gpu_diagnostics.py).  Raise the cap until under 1 % of the sampled chains hit it (at most
+            # half the series), and say what is left: ess_per_sec counts those chains as the kernel reports them (an upper
+            # bracket), ess_per_sec_lower counts them as 0.
+            lag_limit = max(1, (n_kept - burn) // 2)
+            max_lag = min(500, lag_limit)
+            while True:
+                ess, capped = diag.chain_ess(sub, burn, max_lag, return_capped=True)
+                chain_capped = capped.max(dim=0).values > 0  # any coordinate of the chain
+                n_capped = all_sum(chain_capped.sum().item())
+                if n_capped <= 0.01 * n_s * world or max_lag >= lag_limit:
+                    break
+                max_lag = min(2 * max_lag, lag_limit)
             ess_chain = ess.min(dim=0).values  # min over coordinates, per sampled chain
             ess_chain = torch.nan_to_num(ess_chain, nan=0.0, posinf=0.0, neginf=0.0)  # a frozen chain carries no information
-            ess_total = all_sum(ess_chain.mean().item() * n_chains)  # this rank's chains, then the sum over ranks
+            scale = n_chains / n_s
+            ess_total = all_sum(ess_chain.sum().item() * scale)  # this rank's chains, then the sum over ranks
+            ess_lower = all_sum((ess_chain * (~chain_capped)).sum().item() * scale)
             extra["ess_per_sec"] = _finite(ess_total / (elapsed / steps))
+            extra["ess_per_sec_lower"] = _finite(ess_lower / (elapsed / steps))
+            extra["ess_max_lag"] = max_lag
+            extra["ess_lag_capped_fraction"] = n_capped / (n_s * world)
+            extra["ess_sample"] = f"{n_s} chains per rank, {n_kept - burn} kept draws after burn-in, min over coordinates"
     else:
         n_mom = n_iter - n_iter // 2
         mean, var = res["mean"], res["m2"] / max(1, n_mom - 1)

@@ -269,6 +269,30 @@ int mcmc_rwMCMC(const mcmc_target *target, int32_t d, const double *h_init_theta
                 const double *h_Z, const double *h_U, double *h_theta_trace,
                 double *h_acceptance_rate, int32_t *fail_iter);
 
+/* ----- many chains, host pointers: the batch path for an R caller -----------------------
+ * replaces: mclapply_RNG(X, FUN) (MCMCutilty.R:103-149) around FUN = function(x) adaptMCMC(target, x, covmat, ...)
+ *   -- the reference's only way to run several chains: one adaptMCMC call (adaptMCMC_source.cpp:75-219) per element
+ *   of X in a socket-cluster worker, results returned as a list -- by ONE call that runs all chains on the GPU.
+ *   h_init_theta     init_per_chain != 0: d x n_chains column-major, column c = X[[c]] (chain c's init_theta);
+ *                    init_per_chain == 0: [d], one start for all chains
+ *   h_theta_trace    n_chains matrices back to back, chain c at h_theta_trace + c*n_kept*d: n_kept x d column-major,
+ *                    n_kept = n_iterations / thin -- the `trace` element melt_trace (MCMCutilty.R:19-35) reads per
+ *                    chain.  May be NULL.
+ *   h_acceptance_rate [n_chains] or NULL (:218); h_covmat_empirical d x d x n_chains (the last sigma_empirical slice
+ *                    of every chain, :211,214) or NULL; h_status [n_chains] per-chain status words or NULL (a chain
+ *                    whose chol failed has NaN rows from that iteration on; the call itself still returns MCMC_OK).
+ *   seedMH           Philox key, converted as at :78; chain c draws from (seedMH, chain id c), so -- unlike the
+ *                    reference, where every worker handed the same seedMH repeats one std::mt19937 stream -- the
+ *                    chains of one call are independent, and a chain's results do not depend on n_chains.
+ * Same kernels and kernel choice as mcmc_adapt_rwm_batch (bit-identical traces); chains are processed in slabs of at
+ * most 4 GiB of device trace, so the host result may be larger than the GPU's memory.  Synchronous. */
+int mcmc_adaptMCMC_chains(const mcmc_target *target, int32_t d, int64_t n_chains, const double *h_init_theta,
+                          int32_t init_per_chain, const double *h_covmat, int32_t n_iterations,
+                          int32_t adapt_size_start, double acceptance_rate_weight, int32_t acceptance_window,
+                          int32_t adapt_shape_start, int32_t info, double seedMH, double adapt_size_cooling,
+                          double max_scaling_sd, int32_t thin, double *h_theta_trace, double *h_acceptance_rate,
+                          double *h_covmat_empirical, int32_t *h_status);
+
 /* =====================================================================================
  * Truncated multivariate normal Gibbs sampler, many chains
  * replaces: arma::mat rtmvnorm_gibbs(int n, arma::vec mu, arma::mat sigma, arma::vec lower,
@@ -312,15 +336,17 @@ int mcmc_tmvn_gibbs_batch(const mcmc_gibbs_config *cfg, const mcmc_gibbs_io *io,
 
 /*
  * The same call for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc).  No counterpart in the reference.  mcmc_tmvn_gibbs_batch stages its shared
- * parameter block (regression rows P_i, sd_i, bounds: tmvrnormGibbs.cpp:100-113) in a hipMallocAsync'ed buffer and
- * waits for the upload; this variant keeps the block in a static 160 KB device array of the library (one copy per
- * GPU, held until the process ends), fills it through kernel arguments and calls no hipMalloc / hipFree /
- * hipMemcpy / stream synchronisation: every step is a kernel launch on `stream`.  Same kernels, bit-identical results.
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  mcmc_tmvn_gibbs_batch keeps its shared
+ * parameter block (regression rows P_i, sd_i, bounds: tmvrnormGibbs.cpp:100-113) in a hipMallocAsync'ed buffer; this
+ * variant keeps it in a static 160 KB device array of the library (one copy per GPU, held until the process ends).
+ * Both fill the block through the arguments of small kernels, so neither waits for the stream; this one also calls no
+ * hipMalloc / hipFree / hipMemcpy: every step is a kernel launch on `stream`.  Same kernels, bit-identical results.
+ * The FIRST call on a device looks up the array's address (hipGetSymbolAddress, which loads the code object): make one
+ * warm-up call per device outside hipStreamBeginCapture; every later call is launches only and can be captured.
  * Limits: d <= mcmc_tmvn_gibbs_noalloc_max_dim() (= 139: the block of a larger d does not fit the array; MCMC_E_UNSUPPORTED).
- * Every call on a GPU uses that GPU's one array (and one host staging area): calls that overlap on one GPU -- from
- * two host threads, or on two streams while the first call's kernel is still running -- race; calls on different
- * GPUs do not.
+ * Every call on a GPU uses that GPU's one array.  Host threads are serialised per GPU while a call stages and queues
+ * its block (a mutex), but calls that overlap ON THE DEVICE -- on two streams while the first call's kernel is still
+ * running -- race; calls on different GPUs do not.
  */
 int mcmc_tmvn_gibbs_batch_noalloc(const mcmc_gibbs_config *cfg, const mcmc_gibbs_io *io, void *stream);
 int mcmc_tmvn_gibbs_noalloc_max_dim(void);
@@ -340,6 +366,16 @@ int mcmc_gibbs_streams(uint64_t seed, int64_t chain_offset, int64_t n_chains, in
 int mcmc_rtmvnorm_gibbs(int32_t n, int32_t d, const double *h_mu, const double *h_sigma,
                         const double *h_lower, const double *h_upper, const double *h_init_state,
                         const double *h_U, uint64_t seed, double *h_trace);
+
+/* many chains, host pointers: replaces mclapply_RNG(X, FUN) (MCMCutilty.R:103-149) around
+ * FUN = function(x) rtmvnorm_gibbs(n, mu, sigma, lower, upper, x) (tmvrnormGibbs.cpp:91-142).  h_init_state is
+ * d x n_chains column-major (init_per_chain != 0) or [d]; h_trace holds n_chains matrices back to back, each
+ * (n / thin) x d column-major; chain c draws its uniforms from Philox (seed, chain id c); h_status [n_chains] or NULL.
+ * tail_safe as in mcmc_gibbs_config.  Same kernels as mcmc_tmvn_gibbs_batch (bit-identical); synchronous. */
+int mcmc_rtmvnorm_gibbs_chains(int32_t n, int32_t d, int64_t n_chains, const double *h_mu, const double *h_sigma,
+                               const double *h_lower, const double *h_upper, const double *h_init_state,
+                               int32_t init_per_chain, uint64_t seed, int32_t thin, int32_t tail_safe,
+                               double *h_trace, int32_t *h_status);
 
 /* replaces: NumericVector rtnorm_gibbs(int n, double mu, double sigma, double a, double b)
  * (tmvrnormGibbs.cpp:49-70); h_F optional (the runif(n) draws), NULL = Philox(seed). */
@@ -382,6 +418,11 @@ int mcmc_pooled_cov_partial(const double *d_mean, const double *d_cov, int32_t d
  * autocorrelation up to max_lag): d_ess is [d][n_chains]. */
 int mcmc_chain_ess(const double *d_trace, int32_t n_kept, int32_t burn_kept, int32_t d,
                    int64_t n_chains, int32_t max_lag, double *d_ess, void *stream);
+/* The same, and d_capped [d][n_chains] (may be NULL) receives 1 where the sum of autocorrelation pairs was still
+ * positive at max_lag -- the cap, not Geyer's stopping rule, ended it, so that chain's ESS is an UPPER bound
+ * (tau is under-stated) -- and 0 elsewhere.  A constant series has ESS 0, capped 0. */
+int mcmc_chain_ess_capped(const double *d_trace, int32_t n_kept, int32_t burn_kept, int32_t d,
+                          int64_t n_chains, int32_t max_lag, double *d_ess, int32_t *d_capped, void *stream);
 
 /* =====================================================================================
  * Outside the two samplers: the multivariate normal density helpers of

@@ -2,6 +2,10 @@
 // has no R / Rcpp / RcppArmadillo).  It carries the reference's eight exported signatures
 // verbatim (adaptMCMC_source.cpp:74-76,229-230; tmvrnormGibbs.cpp:11-12,19-20,26-27,33-34,48-49,
 // 90-91) and each body is: marshal -> one extern "C" call into libmcmc_amd.so -> wrap.
+// Two more exports, adaptMCMC_chains and rtmvnorm_gibbs_chains (end of file), do the job of
+// mclapply_RNG(X, FUN) (MCMCutilty.R:103-149) in one call: all chains of X in one GPU launch, returned as the
+// list of chains melt_trace (MCMCutilty.R:19-35) reads.  That is the fast path: a single chain per call occupies
+// one lane of a 256-CU GPU and runs ~10x slower than a CPU core.
 //
 // Build inside R:  Sys.setenv(PKG_LIBS = "-L<repo>/mcmc_amd -lmcmc_amd -Wl,-rpath,<repo>/mcmc_amd",
 //                             PKG_CPPFLAGS = "-I<repo>/include");  Rcpp::sourceCpp("rcpp_shim.cpp")
@@ -161,4 +165,64 @@ arma::mat rtmvnorm_gibbs(int n, arma::vec mu, arma::mat sigma, arma::vec lower, 
     check(mcmc_rtmvnorm_gibbs(n, d, mu.memptr(), sigma.memptr(), lower.memptr(), upper.memptr(), init_state.memptr(),
                               U.begin(), 0, trace.memptr()));
     return trace;
+}
+
+// ---- many chains in one call ------------------------------------------------------------------
+// X is what mclapply_RNG's first argument is in the reference (MCMCutilty.R:103): a list of per-chain start
+// vectors.  The return value is what mclapply_RNG returns -- a list with one element per chain -- and every element
+// carries `trace` (iterations x parameters), which is what melt_trace indexes (MCMCutilty.R:22-24), beside
+// `acceptance_rate` and the per-chain `status` word (0 = ran to completion).
+namespace {
+arma::mat starts_as_columns(List X, int &d)
+{
+    if (X.size() == 0) stop("mcmc_amd: X is empty");
+    d = as<arma::vec>(X[0]).n_elem;
+    arma::mat init(d, X.size());
+    for (int c = 0; c < X.size(); ++c) {
+        arma::vec x = as<arma::vec>(X[c]);
+        if ((int)x.n_elem != d) stop("mcmc_amd: X[[%d]] has length %d, X[[1]] has %d", c + 1, (int)x.n_elem, d);
+        init.col(c) = x;
+    }
+    return init;
+}
+} // namespace
+
+// [[Rcpp::export]]
+List adaptMCMC_chains(SEXP target, List X, arma::mat covmat, int n_iterations, int adapt_size_start,
+                      double acceptance_rate_weight, int acceptance_window, int adapt_shape_start, int info, double seedMH,
+                      double adapt_size_cooling = 0.99, double max_scaling_sd = 50.0, int thin = 1)
+{
+    int d = 0;
+    arma::mat init = starts_as_columns(X, d);
+    const int n_chains = init.n_cols, n_kept = thin > 0 ? n_iterations / thin : 0;
+    TargetDesc td = make_target(target, d);
+    arma::cube traces(n_kept, d, n_chains); // slice c = chain c's n_kept x d matrix, column-major: the C ABI's layout
+    arma::vec acc(n_chains);
+    IntegerVector status(n_chains);
+    check(mcmc_adaptMCMC_chains(&td.t, d, n_chains, init.memptr(), 1, covmat.memptr(), n_iterations, adapt_size_start,
+                                acceptance_rate_weight, acceptance_window, adapt_shape_start, info, seedMH,
+                                adapt_size_cooling, max_scaling_sd, thin, traces.memptr(), acc.memptr(), nullptr,
+                                status.begin()));
+    List out(n_chains);
+    for (int c = 0; c < n_chains; ++c)
+        out[c] = List::create(Named("trace") = DataFrame(wrap(arma::mat(traces.slice(c)))), Named("acceptance_rate") = acc[c],
+                              Named("status") = status[c]);
+    return out;
+}
+
+// [[Rcpp::export]]
+List rtmvnorm_gibbs_chains(int n, arma::vec mu, arma::mat sigma, arma::vec lower, arma::vec upper, List X, double seed = 0,
+                           int thin = 1)
+{
+    int d = 0;
+    arma::mat init = starts_as_columns(X, d);
+    const int n_chains = init.n_cols, n_kept = thin > 0 ? n / thin : 0;
+    arma::cube traces(n_kept, d, n_chains);
+    IntegerVector status(n_chains);
+    check(mcmc_rtmvnorm_gibbs_chains(n, d, n_chains, mu.memptr(), sigma.memptr(), lower.memptr(), upper.memptr(),
+                                     init.memptr(), 1, (uint64_t)seed, thin, 0, traces.memptr(), status.begin()));
+    List out(n_chains);
+    for (int c = 0; c < n_chains; ++c)
+        out[c] = List::create(Named("trace") = DataFrame(wrap(arma::mat(traces.slice(c)))), Named("status") = status[c]);
+    return out;
 }

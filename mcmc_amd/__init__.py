@@ -8,7 +8,7 @@ from ._lib import (  # noqa: F401
     MCMC_CHAIN_BAD_STATE, MCMC_CHAIN_CHOL_FAILED, MCMC_CHAIN_NONFINITE_STATE, MCMC_CHAIN_OK, McmcError, lib,
 )
 from .api import (  # noqa: F401
-    RwmState, Target, adaptMCMC, adapt_rwm_batch, gibbs_streams, init_normal, negSubCol, negSubRow, rtmvnorm_gibbs,
+    RwmState, Target, adaptMCMC, adaptMCMC_chains, rtmvnorm_gibbs_chains, adapt_rwm_batch, gibbs_streams, init_normal, negSubCol, negSubRow, rtmvnorm_gibbs,
     rtnorm_batch, rtnorm_gibbs, rwMCMC, rwm_streams, sub1, sub2, target_eval_batch, tmvn_gibbs_batch, tmvn_precompute,
     mvrGaussian_pdf, tmvrGaussian_pdf, pmvnorm, random_walk2d, random_walk3d, random_walk_batch, random_walkGraph,
     random_walkGraph_batch,

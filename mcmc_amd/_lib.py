@@ -105,6 +105,11 @@ SIGNATURES = {
                                  dp, dp, dp, dp, ip]),
     "mcmc_rwMCMC": (C.c_int, [C.POINTER(McmcTarget), C.c_int32, dp, dp, C.c_int32, C.c_int32, C.c_double, dp, dp,
                               dp, dp, ip]),
+    "mcmc_adaptMCMC_chains": (C.c_int, [C.POINTER(McmcTarget), C.c_int32, C.c_int64, dp, C.c_int32, dp, C.c_int32, C.c_int32,
+                                        C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double,
+                                        C.c_int32, dp, dp, dp, ip]),
+    "mcmc_rtmvnorm_gibbs_chains": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, dp, dp, dp, dp, dp, C.c_int32, C.c_uint64,
+                                             C.c_int32, C.c_int32, dp, ip]),
     "mcmc_tmvn_gibbs_batch": (C.c_int, [C.POINTER(GibbsConfig), C.POINTER(GibbsIO), vp]),
     "mcmc_tmvn_gibbs_batch_noalloc": (C.c_int, [C.POINTER(GibbsConfig), C.POINTER(GibbsIO), vp]),
     "mcmc_tmvn_gibbs_noalloc_max_dim": (C.c_int, []),
@@ -122,6 +127,7 @@ SIGNATURES = {
     "mcmc_rhat_partial": (C.c_int, [vp, vp, C.c_int32, C.c_int64, vp, vp]),
     "mcmc_pooled_cov_partial": (C.c_int, [vp, vp, C.c_int32, C.c_int64, vp, vp]),
     "mcmc_chain_ess": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, vp, vp]),
+    "mcmc_chain_ess_capped": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, vp, vp, vp]),
     "mcmc_mvrGaussian_pdf_batch": (C.c_int, [C.c_int32, C.c_int64, vp, dp, dp, C.c_int32, vp, vp]),
     "mcmc_mvrGaussian_pdf": (C.c_int, [C.c_int32, dp, dp, dp, C.c_int32, dp]),
     "mcmc_tmvrGaussian_pdf_batch": (C.c_int, [C.c_int32, C.c_int64, vp, dp, dp, dp, dp, C.c_double, vp, vp]),

@@ -216,6 +216,65 @@ def rtnorm_gibbs(n, mu, sigma, a, b, *, F=None, seed=0):
     return out
 
 
+def _init_matrix(X, d_expected=None):
+    """list / array of per-chain start vectors (R: X[[c]]) -> (d x n_chains column-major flat, d, n_chains)"""
+    X = np.asarray(X, dtype=np.float64)
+    if X.ndim != 2:
+        raise ValueError("X must be a sequence of equally long start vectors (one per chain)")
+    n_chains, d = X.shape
+    if d_expected is not None and d != d_expected:
+        raise ValueError(f"start vectors have length {d}, expected {d_expected}")
+    return np.ascontiguousarray(X).reshape(-1), d, n_chains  # row c of X = column c of the d x n_chains matrix
+
+
+def adaptMCMC_chains(target, X, covmat, n_iterations, adapt_size_start, acceptance_rate_weight, acceptance_window,
+                     adapt_shape_start, info, seedMH, adapt_size_cooling=0.99, max_scaling_sd=50.0, *, thin=1,
+                     covmat_empirical=False):
+    """`mclapply_RNG(X, function(x) adaptMCMC(target, x, covmat, ...))` (MCMCutilty.R:103-149 around
+    adaptMCMC_source.cpp:75-219) as ONE host-pointer call (mcmc_adaptMCMC_chains): X is the list of per-chain
+    init_theta.  Returns the reference's list of chains -- element c is a dict with `trace` (n_kept x d, what
+    melt_trace reads, MCMCutilty.R:19-35), `acceptance_rate`, `status` (and `covmat_empirical` on request)."""
+    t = _need_target(target)
+    init, d, n_chains = _init_matrix(X)
+    cov = _colmajor(covmat, d)
+    n, thin = int(n_iterations), int(thin)
+    n_kept = n // thin if thin > 0 else 0
+    trace = np.empty(n_chains * n_kept * d)
+    acc = np.empty(n_chains)
+    status = np.zeros(n_chains, dtype=np.int32)
+    cemp = np.empty(n_chains * d * d) if covmat_empirical else None
+    ct = t._c()
+    check(lib.mcmc_adaptMCMC_chains(C.byref(ct), d, n_chains, _p(init), 1, _p(cov), n, int(adapt_size_start),
+                                    float(acceptance_rate_weight), int(acceptance_window), int(adapt_shape_start),
+                                    int(info), float(seedMH), float(adapt_size_cooling), float(max_scaling_sd), thin,
+                                    _p(trace), _p(acc), _p(cemp), status.ctypes.data_as(L.ip)))
+    out = []
+    for c in range(n_chains):
+        item = dict(trace=trace[c * n_kept * d:(c + 1) * n_kept * d].reshape(n_kept, d, order="F"),
+                    acceptance_rate=float(acc[c]), status=int(status[c]))
+        if covmat_empirical:
+            item["covmat_empirical"] = cemp[c * d * d:(c + 1) * d * d].reshape(d, d, order="F")
+        out.append(item)
+    return out
+
+
+def rtmvnorm_gibbs_chains(n, mu, sigma, lower, upper, X, *, seed=0, thin=1, tail_safe=False):
+    """`mclapply_RNG(X, function(x) rtmvnorm_gibbs(n, mu, sigma, lower, upper, x))` (MCMCutilty.R:103-149 around
+    tmvrnormGibbs.cpp:91-142) as one host-pointer call (mcmc_rtmvnorm_gibbs_chains): list of {trace, status}."""
+    mu, lower, upper = _vec(mu), _vec(lower), _vec(upper)
+    d = mu.size
+    init, _, n_chains = _init_matrix(X, d)
+    sg = _colmajor(sigma, d)
+    n, thin = int(n), int(thin)
+    n_kept = n // thin if thin > 0 else 0
+    trace = np.empty(n_chains * n_kept * d)
+    status = np.zeros(n_chains, dtype=np.int32)
+    check(lib.mcmc_rtmvnorm_gibbs_chains(n, d, n_chains, _p(mu), _p(sg), _p(lower), _p(upper), _p(init), 1, int(seed), thin,
+                                         int(bool(tail_safe)), _p(trace), status.ctypes.data_as(L.ip)))
+    return [dict(trace=trace[c * n_kept * d:(c + 1) * n_kept * d].reshape(n_kept, d, order="F"), status=int(status[c]))
+            for c in range(n_chains)]
+
+
 def sub1(x, i):
     """x[-i,-i] (tmvrnormGibbs.cpp:12-16), 0-based i."""
     x = np.asarray(x, dtype=np.float64)

@@ -423,6 +423,174 @@ extern "C" int mcmc_rwMCMC(const mcmc_target *target, int32_t d, const double *h
                           h_U, h_theta_trace, nullptr, h_acceptance_rate, nullptr, fail_iter);
 }
 
+// --------------------------------------------------------------------------------------------
+// Many chains, host pointers: what an R caller reaches the batch kernels through.  Replaces the reference's only
+// multi-chain mechanism, one adaptMCMC call per worker process under mclapply_RNG (MCMCutilty.R:103-149), and hands
+// back per-chain matrices in the layout melt_trace (MCMCutilty.R:19-35) reads.  Chains are processed in slabs whose
+// device trace stays below kChainsSlabBytes, so the host-side result may exceed the GPU's memory.
+static constexpr size_t kChainsSlabBytes = (size_t)4 << 30;
+
+// device [n_kept][d][nc] (chain fastest) -> per chain an n_kept x d column-major matrix, chain c at out + c*n_kept*d
+static void untangle_trace(const double *slab, int64_t n_kept, int d, int64_t nc, double *out)
+{
+    constexpr int64_t TB = 64; // blocked over (t, c) so that both sides stay in cache lines
+    for (int k = 0; k < d; ++k)
+        for (int64_t t0 = 0; t0 < n_kept; t0 += TB)
+            for (int64_t c = 0; c < nc; ++c) {
+                double *dst = out + (size_t)c * n_kept * d + (size_t)k * n_kept;
+                const int64_t t1 = t0 + TB < n_kept ? t0 + TB : n_kept;
+                for (int64_t t = t0; t < t1; ++t) dst[t] = slab[((size_t)t * d + k) * nc + c];
+            }
+}
+
+static int slab_chains(int64_t n_chains, int64_t n_kept, int d)
+{
+    const size_t per_chain = (size_t)(n_kept > 0 ? n_kept : 1) * d * sizeof(double);
+    int64_t m = (int64_t)(kChainsSlabBytes / per_chain);
+    m = m < 64 ? 64 : (m / 64) * 64; // whole wavefronts of chains
+    return (int)(m < n_chains ? m : n_chains);
+}
+
+extern "C" int mcmc_adaptMCMC_chains(const mcmc_target *target, int32_t d, int64_t n_chains, const double *h_init_theta,
+                                     int32_t init_per_chain, const double *h_covmat, int32_t n_iterations,
+                                     int32_t adapt_size_start, double acceptance_rate_weight, int32_t acceptance_window,
+                                     int32_t adapt_shape_start, int32_t info, double seedMH, double adapt_size_cooling,
+                                     double max_scaling_sd, int32_t thin, double *h_theta_trace, double *h_acceptance_rate,
+                                     double *h_covmat_empirical, int32_t *h_status)
+{
+    if (!target || !h_init_theta || !h_covmat) return set_error(MCMC_E_BAD_ARG, "mcmc_adaptMCMC_chains: NULL argument");
+    if (d < 1 || n_iterations < 1 || n_chains < 1 || thin < 1)
+        return set_error(MCMC_E_BAD_ARG, "mcmc_adaptMCMC_chains: d, n_chains, n_iterations and thin must be >= 1");
+    if (n_chains > 0x7fffffff) return set_error(MCMC_E_BAD_ARG, "mcmc_adaptMCMC_chains: n_chains too large");
+    if (info <= 0) return set_error(MCMC_E_BAD_ARG, "info=%d must be > 0 (the reference computes i %% info)", info);
+    if (!std::isfinite(seedMH) || seedMH < 0) return set_error(MCMC_E_BAD_ARG, "seedMH must be a finite non-negative number");
+    const int64_t n_kept = n_iterations / thin;
+    const int slab = slab_chains(n_chains, h_theta_trace ? n_kept : 0, d);
+    DevBuf bInit, bT, bAcc, bSt, bCov;
+    std::vector<double> hInit, hSlab, hCov;
+    if (init_per_chain) {
+        MCMC_HIP_CHECK(bInit.alloc((size_t)slab * d * sizeof(double)));
+        hInit.resize((size_t)slab * d);
+    }
+    if (h_theta_trace) {
+        MCMC_HIP_CHECK(bT.alloc((size_t)slab * n_kept * d * sizeof(double)));
+        hSlab.resize((size_t)slab * n_kept * d);
+    }
+    if (h_acceptance_rate) MCMC_HIP_CHECK(bAcc.alloc((size_t)slab * sizeof(double)));
+    if (h_covmat_empirical) {
+        MCMC_HIP_CHECK(bCov.alloc((size_t)slab * d * d * sizeof(double)));
+        hCov.resize((size_t)slab * d * d);
+    }
+    MCMC_HIP_CHECK(bSt.alloc((size_t)slab * sizeof(int32_t)));
+    std::vector<int32_t> hSt(slab);
+    for (int64_t c0 = 0; c0 < n_chains; c0 += slab) {
+        const int64_t nc = n_chains - c0 < slab ? n_chains - c0 : slab;
+        mcmc_rwm_config cfg{};
+        cfg.d = d;
+        cfg.n_iterations = n_iterations;
+        cfg.n_chains = nc;
+        cfg.chain_offset = c0; // Philox counters carry the global chain id: results do not depend on the slab size
+        cfg.adapt_size_start = adapt_size_start;
+        cfg.adapt_shape_start = adapt_shape_start;
+        cfg.acceptance_window = acceptance_window;
+        cfg.thin = thin;
+        cfg.acceptance_rate_weight = acceptance_rate_weight;
+        cfg.adapt_size_cooling = adapt_size_cooling;
+        cfg.max_scaling_sd = max_scaling_sd;
+        cfg.seed = (uint64_t)seedMH;
+        cfg.rng_mode = MCMC_RNG_PHILOX;
+        mcmc_rwm_io io{};
+        io.h_covmat = h_covmat;
+        if (init_per_chain) { // d x n_chains column-major (one column per chain) -> [d][nc]
+            for (int k = 0; k < d; ++k)
+                for (int64_t c = 0; c < nc; ++c) hInit[(size_t)k * nc + c] = h_init_theta[(size_t)(c0 + c) * d + k];
+            MCMC_HIP_CHECK(hipMemcpy(bInit.p, hInit.data(), (size_t)nc * d * sizeof(double), hipMemcpyHostToDevice));
+            io.d_init = bInit.as<double>();
+        } else {
+            io.h_init_theta = h_init_theta;
+        }
+        io.d_trace = h_theta_trace ? bT.as<double>() : nullptr;
+        io.d_acceptance_rate = h_acceptance_rate ? bAcc.as<double>() : nullptr;
+        io.d_final_cov = h_covmat_empirical ? bCov.as<double>() : nullptr;
+        io.d_status = bSt.as<int32_t>();
+        int rc = mcmc_adapt_rwm_batch(target, &cfg, &io, nullptr);
+        if (rc != MCMC_OK) return rc;
+        MCMC_HIP_CHECK(hipDeviceSynchronize());
+        if (h_theta_trace) {
+            MCMC_HIP_CHECK(hipMemcpy(hSlab.data(), bT.p, (size_t)nc * n_kept * d * sizeof(double), hipMemcpyDeviceToHost));
+            untangle_trace(hSlab.data(), n_kept, d, nc, h_theta_trace + (size_t)c0 * n_kept * d);
+        }
+        if (h_acceptance_rate)
+            MCMC_HIP_CHECK(hipMemcpy(h_acceptance_rate + c0, bAcc.p, (size_t)nc * sizeof(double), hipMemcpyDeviceToHost));
+        if (h_covmat_empirical) { // [d*d][nc] -> per chain a d x d column-major matrix
+            MCMC_HIP_CHECK(hipMemcpy(hCov.data(), bCov.p, (size_t)nc * d * d * sizeof(double), hipMemcpyDeviceToHost));
+            for (int e = 0; e < d * d; ++e)
+                for (int64_t c = 0; c < nc; ++c) h_covmat_empirical[(size_t)(c0 + c) * d * d + e] = hCov[(size_t)e * nc + c];
+        }
+        MCMC_HIP_CHECK(hipMemcpy(hSt.data(), bSt.p, (size_t)nc * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (h_status) std::memcpy(h_status + c0, hSt.data(), (size_t)nc * sizeof(int32_t));
+    }
+    return MCMC_OK;
+}
+
+extern "C" int mcmc_rtmvnorm_gibbs_chains(int32_t n, int32_t d, int64_t n_chains, const double *h_mu, const double *h_sigma,
+                                          const double *h_lower, const double *h_upper, const double *h_init_state,
+                                          int32_t init_per_chain, uint64_t seed, int32_t thin, int32_t tail_safe,
+                                          double *h_trace, int32_t *h_status)
+{
+    if (n < 1 || d < 1 || n_chains < 1 || thin < 1 || !h_mu || !h_sigma || !h_lower || !h_upper || !h_init_state || !h_trace)
+        return set_error(MCMC_E_BAD_ARG, "mcmc_rtmvnorm_gibbs_chains: bad argument");
+    if (n_chains > 0x7fffffff) return set_error(MCMC_E_BAD_ARG, "mcmc_rtmvnorm_gibbs_chains: n_chains too large");
+    const int64_t n_kept = n / thin;
+    const int slab = slab_chains(n_chains, n_kept, d);
+    DevBuf bInit, bT, bSt;
+    std::vector<double> hInit, hSlab((size_t)slab * n_kept * d);
+    std::vector<int32_t> hSt(slab);
+    if (init_per_chain) {
+        MCMC_HIP_CHECK(bInit.alloc((size_t)slab * d * sizeof(double)));
+        hInit.resize((size_t)slab * d);
+    }
+    MCMC_HIP_CHECK(bT.alloc((size_t)slab * n_kept * d * sizeof(double)));
+    MCMC_HIP_CHECK(bSt.alloc((size_t)slab * sizeof(int32_t)));
+    for (int64_t c0 = 0; c0 < n_chains; c0 += slab) {
+        const int64_t nc = n_chains - c0 < slab ? n_chains - c0 : slab;
+        mcmc_gibbs_config cfg{};
+        cfg.d = d;
+        cfg.n_sweeps = n;
+        cfg.n_chains = nc;
+        cfg.chain_offset = c0;
+        cfg.thin = thin;
+        cfg.seed = seed;
+        cfg.rng_mode = MCMC_RNG_PHILOX;
+        cfg.tail_safe = tail_safe;
+        mcmc_gibbs_io io{};
+        io.h_mu = h_mu;
+        io.h_sigma = h_sigma;
+        io.h_lower = h_lower;
+        io.h_upper = h_upper;
+        if (init_per_chain) {
+            for (int k = 0; k < d; ++k)
+                for (int64_t c = 0; c < nc; ++c) hInit[(size_t)k * nc + c] = h_init_state[(size_t)(c0 + c) * d + k];
+            MCMC_HIP_CHECK(hipMemcpy(bInit.p, hInit.data(), (size_t)nc * d * sizeof(double), hipMemcpyHostToDevice));
+            io.d_init = bInit.as<double>();
+        } else {
+            io.h_init_state = h_init_state;
+        }
+        io.d_trace = bT.as<double>();
+        io.d_status = bSt.as<int32_t>();
+        int rc = mcmc_tmvn_gibbs_batch(&cfg, &io, nullptr);
+        if (rc != MCMC_OK) return rc;
+        MCMC_HIP_CHECK(hipDeviceSynchronize());
+        MCMC_HIP_CHECK(hipMemcpy(hSlab.data(), bT.p, (size_t)nc * n_kept * d * sizeof(double), hipMemcpyDeviceToHost));
+        untangle_trace(hSlab.data(), n_kept, d, nc, h_trace + (size_t)c0 * n_kept * d);
+        if (h_status) {
+            MCMC_HIP_CHECK(hipMemcpy(hSt.data(), bSt.p, (size_t)nc * sizeof(int32_t), hipMemcpyDeviceToHost));
+            std::memcpy(h_status + c0, hSt.data(), (size_t)nc * sizeof(int32_t));
+        }
+    }
+    return MCMC_OK;
+}
+
 // ============================================================================================
 extern "C" int mcmc_tmvn_precompute(int32_t d, const double *h_sigma, double *h_P, double *h_sd)
 {

@@ -95,9 +95,12 @@ __global__ __launch_bounds__(1024) void pooled_cov_partial_kernel(const double *
     }
 }
 
-// Geyer initial-positive-sequence ESS, one thread per (chain, coordinate)
+// Geyer initial-positive-sequence ESS, one thread per (chain, coordinate).  `capped_out` (may be NULL) receives 1
+// where the sum of autocorrelation pairs was still positive at max_lag, i.e. where the truncation -- not Geyer's
+// stopping rule -- ended it and the ESS is therefore OVER-stated (tau under-stated); 0 otherwise.
 __global__ __launch_bounds__(256) void chain_ess_kernel(const double *__restrict__ trace, int32_t n_kept, int32_t burn,
-                                                        int32_t d, int64_t n, int32_t max_lag, double *ess_out)
+                                                        int32_t d, int64_t n, int32_t max_lag, double *ess_out,
+                                                        int32_t *capped_out)
 {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int k = blockIdx.y;
@@ -105,33 +108,67 @@ __global__ __launch_bounds__(256) void chain_ess_kernel(const double *__restrict
     const int N = n_kept - burn;
     const double *x = trace + ((int64_t)burn * d + k) * n + c;
     const int64_t stride = (int64_t)d * n;
-    double mean = 0.0;
-    for (int t = 0; t < N; ++t) mean += x[t * stride];
+    double mean = 0.0, lo = x[0], hi = x[0];
+    for (int t = 0; t < N; ++t) {
+        const double xt = x[t * stride];
+        mean += xt;
+        lo = fmin(lo, xt);
+        hi = fmax(hi, xt);
+    }
     mean /= N;
     double g0 = 0.0;
     for (int t = 0; t < N; ++t) {
         const double v = x[t * stride] - mean;
         g0 += v * v;
     }
+    // a chain that never moved carries no information: ESS 0.  Decided on the values themselves, because the rounded
+    // mean of N equal numbers need not equal them, which leaves a g0 of rounding noise (and an ESS of ~1) behind.
+    if (!(hi > lo)) g0 = 0.0;
     double ess = 0.0;
+    int32_t capped = 0;
     if (g0 > 0.0 && N > 1) {
         double tau = -1.0;
         const int kmax = max_lag < N - 1 ? max_lag : N - 1;
-        for (int lag = 0; lag <= kmax; lag += 2) {
-            double ga = 0.0, gb = 0.0;
-            for (int t = 0; t + lag < N; ++t) {
-                const double v = x[t * stride] - mean;
-                ga += v * (x[(t + lag) * stride] - mean);
-                if (t + lag + 1 < N) gb += v * (x[(t + lag + 1) * stride] - mean);
+        capped = kmax < N - 1; // cleared when Geyer's rule stops the sum before the cap does
+        // Eight lags per pass over the series: w[] is a sliding window of the eight values v[t+lag0 .. t+lag0+7] (zero
+        // past the end, so a term beyond the series adds nothing), rotated statically by unrolling t by eight, which
+        // makes it two loads per t for eight autocovariances.  Each sum runs over t in ascending order.
+        auto val = [&](int idx) { return idx < N ? x[idx * stride] - mean : 0.0; };
+        bool done = false;
+        for (int lag0 = 0; lag0 <= kmax && !done; lag0 += 8) {
+            double g[8], w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                g[j] = 0.0;
+                w[j] = val(lag0 + j);
             }
-            if (lag + 1 > kmax) gb = 0.0;
-            const double pair = (ga + gb) / g0;
-            if (pair <= 0.0) break;
-            tau += 2.0 * pair;
+            for (int t0 = 0; t0 + lag0 < N; t0 += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double a = val(t0 + u);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g[j] += a * w[(u + j) & 7];
+                    w[u] = val(t0 + u + lag0 + 8);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const int lag = lag0 + j;
+                if (done || lag > kmax) continue;
+                const double gb = lag + 1 > kmax ? 0.0 : g[j + 1];
+                const double pair = (g[j] + gb) / g0;
+                if (pair <= 0.0) {
+                    capped = 0;
+                    done = true;
+                } else {
+                    tau += 2.0 * pair;
+                }
+            }
         }
         ess = tau > 0.0 ? N / tau : (double)N;
     }
     ess_out[(int64_t)k * n + c] = ess;
+    if (capped_out) capped_out[(int64_t)k * n + c] = capped;
 }
 
 } // namespace mcmc
@@ -172,14 +209,20 @@ extern "C" int mcmc_pooled_cov_partial(const double *d_mean, const double *d_cov
     return MCMC_OK;
 }
 
-extern "C" int mcmc_chain_ess(const double *d_trace, int32_t n_kept, int32_t burn_kept, int32_t d, int64_t n_chains,
-                              int32_t max_lag, double *d_ess, void *stream)
+extern "C" int mcmc_chain_ess_capped(const double *d_trace, int32_t n_kept, int32_t burn_kept, int32_t d, int64_t n_chains,
+                                     int32_t max_lag, double *d_ess, int32_t *d_capped, void *stream)
 {
     if (!d_trace || !d_ess || d < 1 || n_chains < 1 || burn_kept < 0 || n_kept <= burn_kept || max_lag < 1)
         return set_error(MCMC_E_BAD_ARG, "mcmc_chain_ess: bad argument");
-    dim3 grid((unsigned)((n_chains + 255) / 256), (unsigned)d);
-    hipLaunchKernelGGL(chain_ess_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_trace, n_kept, burn_kept, d,
-                       n_chains, max_lag, d_ess);
+    dim3 grid((unsigned)((n_chains + 63) / 64), (unsigned)d);
+    hipLaunchKernelGGL(chain_ess_kernel, grid, dim3(64), 0, (hipStream_t)stream, d_trace, n_kept, burn_kept, d,
+                       n_chains, max_lag, d_ess, d_capped);
     MCMC_HIP_CHECK(hipGetLastError());
     return MCMC_OK;
+}
+
+extern "C" int mcmc_chain_ess(const double *d_trace, int32_t n_kept, int32_t burn_kept, int32_t d, int64_t n_chains,
+                              int32_t max_lag, double *d_ess, void *stream)
+{
+    return mcmc_chain_ess_capped(d_trace, n_kept, burn_kept, d, n_chains, max_lag, d_ess, nullptr, stream);
 }

@@ -615,6 +615,11 @@ int launch_gibbs_noalloc(const GibbsArgs &a, const GibbsParams &p, bool tail_saf
     int dev = 0;
     int rc = gibbs_scratch_ptr(&ptr, &dev);
     if (rc != MCMC_OK) return rc;
+    // One host thread at a time per device from here to the sampling kernel's launch: the staging array is shared, and the
+    // fill launches of two calls must not interleave on their way into the device array.  (This orders the HOST side
+    // only; two calls on different streams can still overlap on the device -- the header documents that race.)
+    static std::mutex stage_mu[kMaxDevices];
+    std::lock_guard<std::mutex> lock(stage_mu[dev]);
     // the whole block of this call is written (padding included), so nothing of the previous call's contents is read
     double *const blk = g_gibbs_stage[dev];
     build_gibbs_block(p, blk);

@@ -28,14 +28,21 @@ def chain_moments(trace, burn_kept=0):
     return mean, var
 
 
-def chain_ess(trace, burn_kept=0, max_lag=1000):
-    """Per-chain, per-coordinate effective sample size, [d, n_chains]."""
+def chain_ess(trace, burn_kept=0, max_lag=1000, return_capped=False):
+    """Per-chain, per-coordinate effective sample size, [d, n_chains] (Geyer's initial positive sequence, summed up
+    to `max_lag`).  With return_capped also an int32 [d, n_chains] array: 1 where the sum was still positive at
+    max_lag, i.e. where the cap ended it and the ESS is over-stated."""
     torch = _torch()
     n_kept, d, n = trace.shape
     ess = torch.empty((d, n), dtype=torch.float64, device=trace.device)
-    check(lib.mcmc_chain_ess(_dev_ptr(trace), n_kept, int(burn_kept), d, n, int(max_lag), _dev_ptr(ess),
-                             _stream_ptr()))
-    return ess
+    if not return_capped:
+        check(lib.mcmc_chain_ess(_dev_ptr(trace), n_kept, int(burn_kept), d, n, int(max_lag), _dev_ptr(ess),
+                                 _stream_ptr()))
+        return ess
+    capped = torch.empty((d, n), dtype=torch.int32, device=trace.device)
+    check(lib.mcmc_chain_ess_capped(_dev_ptr(trace), n_kept, int(burn_kept), d, n, int(max_lag), _dev_ptr(ess),
+                                    _dev_ptr(capped), _stream_ptr()))
+    return ess, capped
 
 
 def rhat_partial(mean, var):

@@ -16,6 +16,22 @@ def _params(d, rho):
     return 0.05 * k, sigma, lower, upper
 
 
+def _pool_used_high(reset=False):
+    """bytes ever handed out by the device's default stream-ordered pool (hipMallocAsync) since the last reset: the
+    allocating entry point raises it, the no-allocation one must not (torch's own counters do not see hipMalloc* calls
+    made inside libmcmc_amd.so)"""
+    import ctypes as C
+
+    hip = C.CDLL("libamdhip64.so")
+    pool = C.c_void_p()
+    assert hip.hipDeviceGetDefaultMemPool(C.byref(pool), 0) == 0
+    val = C.c_uint64(0)
+    if reset:
+        assert hip.hipMemPoolSetAttribute(pool, 0x8, C.byref(val)) == 0  # hipMemPoolAttrUsedMemHigh := 0
+    assert hip.hipMemPoolGetAttribute(pool, 0x8, C.byref(val)) == 0
+    return val.value
+
+
 def _run(cuda, d, n_chains, n_sweeps, seed, no_alloc, **kw):
     import mcmc_amd
 
@@ -64,3 +80,21 @@ def test_noalloc_entry_rejects_what_does_not_fit_the_scratch(cuda):
     r = _run(cuda, dmax, 64, 2, 3, True)  # the largest d that fits
     w = _run(cuda, dmax, 64, 2, 3, False)
     assert cuda.equal(r["trace"], w["trace"])
+
+
+def test_noalloc_entry_allocates_nothing_on_the_device(cuda):
+    """torch.cuda.memory_allocated() only sees torch's caching allocator.  Here: the free device memory
+    (hipMemGetInfo) and the high-water mark of the stream-ordered pool are unchanged across a no-allocation call,
+    while the allocating entry point does move the pool's mark (so the probe can tell the two apart)."""
+    _run(cuda, 100, 130, 5, 1, True)   # warm-up: code objects loaded, the scratch address looked up
+    _run(cuda, 100, 130, 5, 1, False)
+    cuda.cuda.synchronize()
+    _pool_used_high(reset=True)
+    free0 = cuda.cuda.mem_get_info()[0]
+    _run(cuda, 100, 130, 5, 2, True)
+    cuda.cuda.synchronize()
+    assert _pool_used_high() == 0
+    assert cuda.cuda.mem_get_info()[0] == free0
+    _run(cuda, 100, 130, 5, 2, False)
+    cuda.cuda.synchronize()
+    assert _pool_used_high() > 0       # the allocating variant's hipMallocAsync is what the probe sees
