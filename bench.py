@@ -17,6 +17,10 @@ path over that batch = ONE kernel launch advancing every chain by n_iterations.
        adaptation off, adapt_shape_start 1000 -- ~45 % of the iterations factor covmat_empirical
   c5   TMVN Gibbs d=128, lower = +4 conditional sd, upper = +Inf (tail path), per-GPU share of
        config 5: 1,048,576 chains x 200 sweeps, last state + running moments only
+  r32  adaptive RW Metropolis d=32 on the one-chain-per-lane-row kernel (rwm_row_kernel, 12 < d <= 64): Sigma=AA'/d+I,
+       65,536 chains x 3,000 iterations, covmat (0.3/d) I, size adaptation off, adapt_shape_start 180 (most
+       iterations factor covmat_empirical), full trace (50 GB)
+  r64  the same at d=64 (one chain per wavefront): 32,768 chains x 3,000 iterations, full trace (50 GB)
 
 --gpus N: one process per GPU.  Under torch.distributed.run (WORLD_SIZE set) this process is one rank;
 run plainly with N > 1 it starts N fresh child ranks of itself BEFORE anything touches the GPU (the job of
@@ -45,7 +49,7 @@ sys.path.insert(0, ROOT)
 
 FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (= FP64 matrix peak)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-PROFILE_ROUNDS = ("r2", "r1")  # newest committed rocprofv3 PMC summary first
+PROFILE_ROUNDS = ("r3", "r2", "r1")  # newest committed rocprofv3 PMC summary first
 
 
 def rwm_flops_per_iter(d, with_chol):
@@ -228,7 +232,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c4s", "c5"], default="c2")
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c4s", "c5", "r32", "r64"], default="c2")
     ap.add_argument("--chains", type=int, default=None, help="chains per GPU (default: the workload's)")
     ap.add_argument("--iters", type=int, default=None, help="iterations / sweeps (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -277,13 +281,13 @@ def main():
 
     wl = args.workload
     defaults = {"c2": (65536, 10000, 20, 3), "c3": (1 << 20, 2000, 5, 2), "c4": (131072, 5000, 1, 0),
-                "c4s": (131072, 5000, 1, 0), "c5": (1 << 20, 200, 2, 1)}
+                "c4s": (131072, 5000, 1, 0), "c5": (1 << 20, 200, 2, 1), "r32": (65536, 3000, 3, 1), "r64": (32768, 3000, 3, 1)}
     n_chains = args.chains or defaults[wl][0]
     n_iter = args.iters or defaults[wl][1]
     steps = args.steps if args.steps is not None else defaults[wl][2]
     warmup = args.warmup if args.warmup is not None else defaults[wl][3]
     chain_offset = rank * n_chains
-    is_rwm = wl in ("c2", "c4", "c4s")
+    is_rwm = wl in ("c2", "c4", "c4s", "r32", "r64")
 
     if args.rehearse:
         def fence():
@@ -325,6 +329,12 @@ def main():
             desc = (f"C4 (per-GPU share, as specified): adaptive RW Metropolis, {d}-D Gaussian Sigma=AA'/d+I, {n_chains} chains/GPU x "
                     f"{n_iter} iterations, covmat I, adapt 200/1000, trace thinned x10 -- the reference's size adaptation ends in "
                     f"permanent NaN-reject on these inputs (see nan_reject_fraction)")
+        elif wl in ("r32", "r64"):
+            d = 32 if wl == "r32" else 64
+            ass, ashs, thin, init_sd, c0 = 0, 180, 1, 1.0, 0.3 / d
+            Sig = c4_sigma(d)
+            desc = (f"{wl.upper()}: adaptive RW Metropolis on the lane-row kernel, {d}-D Gaussian Sigma=AA'/d+I, {n_chains} chains/GPU x "
+                    f"{n_iter} iterations, covmat (0.3/d) I, size adaptation off, adapt_shape_start 180, full trace to HBM")
         else:
             d, ass, ashs, thin, init_sd, c0 = 100, 0, 1000, 10, 1.0, 0.05
             Sig = c4_sigma(d)
@@ -465,7 +475,7 @@ def main():
         if is_rwm:
             flops_launch = units * rwm_flops_per_iter(d, False) + shape_iters * (d ** 3) / 3.0
             kept = n_iter // thin
-            kernel = f"rwm_pair_kernel<{d},gaussian>" if d <= 10 else "rwm_block_kernel"
+            kernel = f"rwm_pair_kernel<{d},gaussian>" if d <= 10 else ("rwm_row_kernel" if d <= 64 else "rwm_block_kernel")
             per_unit = {"flops_size_phase": rwm_flops_per_iter(d, False), "flops_shape_phase": rwm_flops_per_iter(d, True)}
             unit = "chain-iterations/s"
             metric = "chain-iterations/sec (adaptive RW Metropolis, whole job)"

@@ -52,7 +52,10 @@ __device__ __forceinline__ void row_unroll(F &&f)
 // A VGPR written by a VALU instruction must not be read through DPP for two wait states.  The compiler keeps that
 // rule for its own DPP instructions but cannot see into the asm below, so every value that is about to become a DPP
 // operand passes through this fence once: the s_nop sits behind the instruction that produced x and ahead of every
-// later use of it.
+// later use of it.  Nothing in the language ties the fence to the asm blocks below -- a register copy the compiler
+// inserts between the two (a live-range split, an AGPR read under pressure) would be read too early -- so the BUILD pins
+// it: tools/check_dpp_hazard.py disassembles the code object and tests/test_abi_and_host.py fails if any DPP instruction
+// reads a VGPR that a VALU instruction wrote within the two preceding wait states.
 __device__ __forceinline__ double dpp_ready(double x)
 {
     asm volatile("s_nop 1" : "+v"(x));

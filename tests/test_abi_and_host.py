@@ -190,3 +190,37 @@ __device__ double mcmc_user_target(const double (&x)[MCMC_USER_D], const double 
         mcmc_amd.Target.compile(src, 129, [2.0])
     with pytest.raises(ValueError):
         t.with_params([1.0, 2.0])
+
+
+def test_hand_written_dpp_blocks_keep_the_valu_write_hazard_distance():
+    """ADVICE r2 (rwm_row.hip): the v_fmac_f64_dpp asm blocks rely on an s_nop placed where their operand is created; the
+    compiler does not see DPP reads inside inline asm.  tools/check_dpp_hazard.py disassembles the built gfx950 code and
+    fails if any DPP instruction reads a VGPR that a VALU instruction wrote within the two preceding wait states."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("check_dpp_hazard", os.path.join(ROOT, "tools", "check_dpp_hazard.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    # the checker itself: a VALU write followed at once by a DPP read of that register is a violation, two wait states cure it
+    write = ("v_mul_f64", ["v[20:21]", "v[2:3]", "v[4:5]"])
+    dpp = ("v_fmac_f64_dpp", ["v[22:23]", "v[20:21]", "v[6:7] row_newbcast:0 row_mask:0xf bank_mask:0xf"])
+    other = ("v_add_f64", ["v[30:31]", "v[2:3]", "v[4:5]"])
+    assert len(chk.violations([write, dpp])) == 1
+    assert len(chk.violations([write, other, dpp])) == 1
+    assert chk.violations([write, other, other, dpp]) == []
+    assert chk.violations([write, ("s_nop", ["1"]), dpp]) == []
+    assert len(chk.violations([write, ("s_nop", ["0"]), dpp])) == 1
+    assert chk.violations([("ds_read_b64", ["v[20:21]", "v9"]), dpp]) == []  # not a VALU write: waitcnt's business
+    if not os.path.exists(chk.OBJDUMP):
+        pytest.skip("no llvm-objdump")
+    for name in ("rwm_row.o", "rwm_block.o"):
+        obj = os.path.join(ROOT, "mcmc_amd", "csrc", name)
+        if not os.path.exists(obj):
+            pytest.skip(f"{name} not built in-tree")
+        insts = chk.disassemble(obj)
+        n_dpp = sum(1 for mn, _ in insts if mn.endswith("_dpp"))
+        assert n_dpp > 100, (name, n_dpp)
+        assert chk.violations(insts) == [], name
+    # and the fences are what keeps it so: without the s_nops the same code WOULD violate the rule
+    insts = [i for i in chk.disassemble(os.path.join(ROOT, "mcmc_amd", "csrc", "rwm_row.o")) if i[0] != "s_nop"]
+    assert len(chk.violations(insts)) > 0
