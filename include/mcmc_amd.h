@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define MCMC_AMD_ABI_VERSION 1
+#define MCMC_AMD_ABI_VERSION 2 /* 2: mcmc_rwm_config grew factor_update / refresh_every / trace_layout */
 
 /* ----- return codes ---------------------------------------------------------------- */
 #define MCMC_OK 0
@@ -82,6 +82,22 @@ extern "C" {
 #define MCMC_KERNEL_ROW 4    /* one chain per row of 16 (d <= 16), 32 (d <= 32) or 64 lanes (d <= 64) of a wavefront, one coordinate
                                 and one matrix column per lane; Gaussian target, Philox streams, no per-iteration
                                 diagnostics.  What AUTO runs for 12 < d <= 64 when it serves the request   */
+
+/* ----- how the proposal factor follows covmat_empirical in the shape phase ------------ */
+#define MCMC_FACTOR_EXACT 0  /* the reference: a fresh chol(covmat_proposal) every iteration (adaptMCMC_source.cpp:153);
+                                the parity mode and the default                                                   */
+#define MCMC_FACTOR_RANK1 1  /* NOT a parity mode.  update_sigma (:42-45) changes covmat_empirical by a rank-1 term, so
+                                its factor is updated in O(d^2) -- R_i = sqrt(a) chol(I + p p^T) R_{i-1}, p the whitened
+                                residual, in closed form, no d-step recurrence -- and refactored from covmat_empirical
+                                every refresh_every iterations (absolute iteration numbers).  Same algorithm in exact
+                                arithmetic; trajectories follow the exact mode to rounding drift until a decision
+                                flips (DESIGN.md has the measured drift).  Per-workgroup kernel only (d > 12)       */
+
+/* ----- layout of d_trace ------------------------------------------------------------------ */
+#define MCMC_TRACE_SOA 0          /* [n_kept][d][n_chains], chain fastest: the default, what every other call reads */
+#define MCMC_TRACE_CHAIN_MAJOR 1  /* [n_chains][n_kept][d]: a kept row of a chain is d contiguous doubles.  For the
+                                     kernels that give a chain a whole wavefront or workgroup (MCMC_KERNEL_ROW at
+                                     32 < d <= 64, MCMC_KERNEL_BLOCK), whose SoA stores fill 8 bytes of a line each    */
 
 /* ----- target log-densities --------------------------------------------------------- */
 /*
@@ -169,6 +185,10 @@ typedef struct mcmc_rwm_config {
     int32_t iter_offset;           /* resume: iterations already done (0 = fresh start). This call runs iterations
                                       iter_offset+1 .. iter_offset+n_iterations and needs io->d_state_in;
                                       iter_offset + n_iterations < 2^27 (the status word holds the iteration)   */
+    int32_t factor_update;         /* MCMC_FACTOR_EXACT (0, the reference) | MCMC_FACTOR_RANK1                    */
+    int32_t refresh_every;         /* MCMC_FACTOR_RANK1: full refactorization when iteration % refresh_every == 0 (>= 1) */
+    int32_t trace_layout;          /* MCMC_TRACE_SOA (0) | MCMC_TRACE_CHAIN_MAJOR                                 */
+    int32_t reserved_;             /* 0                                                                          */
 } mcmc_rwm_config;
 
 typedef struct mcmc_rwm_io {

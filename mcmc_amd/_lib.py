@@ -32,6 +32,11 @@ MCMC_KERNEL_BLOCK = 2
 MCMC_KERNEL_PAIR = 3
 MCMC_KERNEL_ROW = 4
 
+MCMC_FACTOR_EXACT = 0
+MCMC_FACTOR_RANK1 = 1
+MCMC_TRACE_SOA = 0
+MCMC_TRACE_CHAIN_MAJOR = 1
+
 MCMC_TARGET_GAUSSIAN_PREC = 0
 MCMC_TARGET_GOLDSTEIN_PRICE = 1
 MCMC_TARGET_BANANA = 2
@@ -55,6 +60,7 @@ class RwmConfig(C.Structure):
         ("acceptance_rate_weight", C.c_double), ("adapt_size_cooling", C.c_double),
         ("max_scaling_sd", C.c_double),
         ("seed", C.c_uint64), ("rng_mode", C.c_int32), ("kernel", C.c_int32), ("iter_offset", C.c_int32),
+        ("factor_update", C.c_int32), ("refresh_every", C.c_int32), ("trace_layout", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -148,6 +154,10 @@ def _load():
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C mcmc_amd/csrc`)."
         )
+    try:  # torch ships its own copy of the HIP runtime: load it first, so that this library binds the runtime whose
+        import torch  # noqa: F401  device buffers and streams it is handed (otherwise: "no ROCm-capable device")
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it

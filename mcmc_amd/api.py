@@ -349,8 +349,14 @@ def adapt_rwm_batch(target, n_chains, init_theta, covmat, n_iterations, adapt_si
                     acceptance_rate_weight=0.0, acceptance_window=0, adapt_shape_start=0, *, seed=0,
                     adapt_size_cooling=0.99, max_scaling_sd=50.0, thin=1, chain_offset=0, Z=None, U=None,
                     trace=True, sigma_trace=False, final=True, diagnostics=False, out=None, device="cuda",
-                    kernel="auto", checkpoint=False, resume=None):
+                    kernel="auto", checkpoint=False, resume=None, factor_update="exact", refresh_every=64,
+                    trace_layout="soa"):
     """Many independent adaptMCMC chains in one launch (adaptMCMC_source.cpp:75-219 per chain).
+
+    factor_update="rank1" (NOT a parity mode; per-workgroup kernel, d > 12): in the shape phase the proposal factor
+    follows covmat_empirical by closed-form rank-1 updates and is refactored every `refresh_every` iterations, instead
+    of the reference's fresh chol every iteration (:153).  trace_layout="chain_major" stores theta_trace as
+    [n_chains, n_kept, d] (a kept row of a chain contiguous; row / per-workgroup kernels, d > 12).
 
     init_theta: length-d vector shared by all chains, or a [d, n_chains] CUDA tensor.
     Z [n_iterations, d, n_chains], U [n_iterations, n_chains]: injected streams (CUDA, f64).
@@ -409,7 +415,10 @@ def adapt_rwm_batch(target, n_chains, init_theta, covmat, n_iterations, adapt_si
                       rng_mode=L.MCMC_RNG_INJECTED if Z is not None else L.MCMC_RNG_PHILOX,
                       kernel={"auto": L.MCMC_KERNEL_AUTO, "lane": L.MCMC_KERNEL_LANE, "block": L.MCMC_KERNEL_BLOCK,
                               "pair": L.MCMC_KERNEL_PAIR, "row": L.MCMC_KERNEL_ROW}[kernel],
-                      iter_offset=i0)
+                      iter_offset=i0,
+                      factor_update={"exact": L.MCMC_FACTOR_EXACT, "rank1": L.MCMC_FACTOR_RANK1}[factor_update],
+                      refresh_every=int(refresh_every),
+                      trace_layout={"soa": L.MCMC_TRACE_SOA, "chain_major": L.MCMC_TRACE_CHAIN_MAJOR}[trace_layout])
     if (Z is None) != (U is None):
         raise ValueError("give both Z and U, or neither")
     if Z is not None:
@@ -421,7 +430,8 @@ def adapt_rwm_batch(target, n_chains, init_theta, covmat, n_iterations, adapt_si
     io.h_covmat = _p(cov)
     io.d_Z = _dev_ptr(Z, f64)
     io.d_U = _dev_ptr(U, f64)
-    io.d_trace = _dev_ptr(buf("theta_trace", (n_kept, d, n_chains), want=trace))
+    io.d_trace = _dev_ptr(buf("theta_trace", (n_chains, n_kept, d) if trace_layout == "chain_major" else (n_kept, d, n_chains),
+                              want=trace))
     io.d_sigma_trace = _dev_ptr(buf("sigma_empirical", (n_kept, d * d, n_chains), want=sigma_trace))
     io.d_final_theta = _dev_ptr(buf("final_theta", (d, n_chains), want=final))
     io.d_final_mean = _dev_ptr(buf("final_mean", (d, n_chains), want=final))

@@ -154,6 +154,23 @@ extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_co
                          (long long)cfg->iter_offset + cfg->n_iterations);
     if ((cfg->iter_offset > 0) != (io->d_state_in != nullptr))
         return set_error(MCMC_E_BAD_ARG, "resume needs both iter_offset > 0 and d_state_in (a fresh start neither)");
+    if (cfg->factor_update != MCMC_FACTOR_EXACT && cfg->factor_update != MCMC_FACTOR_RANK1)
+        return set_error(MCMC_E_BAD_ARG, "unknown factor_update %d", cfg->factor_update);
+    if (cfg->trace_layout != MCMC_TRACE_SOA && cfg->trace_layout != MCMC_TRACE_CHAIN_MAJOR)
+        return set_error(MCMC_E_BAD_ARG, "unknown trace_layout %d", cfg->trace_layout);
+    const bool rank1 = cfg->factor_update == MCMC_FACTOR_RANK1, chain_major = cfg->trace_layout == MCMC_TRACE_CHAIN_MAJOR;
+    if (rank1) {
+        if (cfg->refresh_every < 1) return set_error(MCMC_E_BAD_ARG, "MCMC_FACTOR_RANK1 needs refresh_every >= 1, got %d", cfg->refresh_every);
+        if (d <= kMaxLaneDimRwm || (cfg->kernel != MCMC_KERNEL_AUTO && cfg->kernel != MCMC_KERNEL_BLOCK))
+            return set_error(MCMC_E_UNSUPPORTED, "MCMC_FACTOR_RANK1 is served by the per-workgroup kernel only (d > %d, kernel AUTO or BLOCK)", kMaxLaneDimRwm);
+        if (target->kind != MCMC_TARGET_GAUSSIAN_PREC)
+            return set_error(MCMC_E_UNSUPPORTED, "MCMC_FACTOR_RANK1 serves the Gaussian target only");
+        if (cfg->rng_mode == MCMC_RNG_INJECTED || io->d_sigma_trace || io->d_accepted || io->d_log_acceptance || io->d_log_A || io->d_scaling_sd ||
+            io->d_scaling_multiplier || io->d_rate_trace)
+            return set_error(MCMC_E_UNSUPPORTED, "MCMC_FACTOR_RANK1 is not a parity mode: no injected streams, sigma_empirical trace or per-iteration diagnostics");
+    }
+    if (chain_major && (d <= kMaxLaneDimRwm || cfg->kernel == MCMC_KERNEL_LANE || cfg->kernel == MCMC_KERNEL_PAIR))
+        return set_error(MCMC_E_UNSUPPORTED, "MCMC_TRACE_CHAIN_MAJOR is served by the per-row and per-workgroup kernels only (d > %d)", kMaxLaneDimRwm);
     if (cfg->kernel == MCMC_KERNEL_LANE && d > kMaxLaneDimRwm)
         return set_error(MCMC_E_UNSUPPORTED, "one-chain-per-lane kernel: d=%d above its limit %d", d, kMaxLaneDimRwm);
     if (cfg->kernel == MCMC_KERNEL_ROW && d > kMaxRowDimRwm)
@@ -202,6 +219,10 @@ extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_co
     a.iter_offset = cfg->iter_offset;
     a.d_state_in = io->d_state_in;
     a.d_state_out = io->d_state_out;
+    a.factor_rank1 = rank1 ? 1 : 0;
+    a.refresh_every = rank1 ? cfg->refresh_every : 1;
+    a.trace_chain_major = chain_major ? 1 : 0;
+    a.n_kept = (int64_t)(cfg->iter_offset + cfg->n_iterations) / cfg->thin - (int64_t)cfg->iter_offset / cfg->thin;
 
     // per-call device scratch: the cooling table and, for acceptance_window > 64, the outcome ring; both are released
     // on every path out of this function

@@ -117,6 +117,13 @@ struct RwmArgs {
     // acceptance_window > 64 (accept_window.h): the outcome ring, [win_words][n_chains] 64-bit words, zeroed by the host
     unsigned long long *d_win_ring;
     int32_t win_words;
+    // MCMC_FACTOR_RANK1 (per-workgroup kernel): the factor follows covmat_empirical by closed-form rank-1 updates and is
+    // refactored when the iteration is a multiple of refresh_every
+    int32_t factor_rank1;
+    int32_t refresh_every;
+    // MCMC_TRACE_CHAIN_MAJOR: d_trace is [n_chains][n_kept][d]; n_kept = rows this launch keeps
+    int32_t trace_chain_major;
+    int64_t n_kept;
 };
 
 #ifndef __HIPCC_RTC__
@@ -179,17 +186,20 @@ enum RwmStateScalar {
     ST_BASE,      // 1 when R factors covmat_empirical
     ST_STATUS, ST_NSHAPE,
     ST_WCOUNT,    // acceptance window > 64: accepted outcomes held
+    ST_FAST,      // MCMC_FACTOR_RANK1: 1 when R tracks chol(covmat_empirical) and Q holds the whitened residual
     kRwmStateScalars
 };
 // With acceptance_window > 64 the state continues behind TOTAL with the outcome ring: word w as two 32-bit halves at
 // TOTAL + 2 w, TOTAL + 2 w + 1 (mcmc_rwm_state_doubles_window).
+// Q (per-workgroup kernel): the last residual theta - theta_mean [d], then its whitened form R^-T r [d] -- what a
+// MCMC_FACTOR_RANK1 run needs to continue its factor updates bit for bit; the other kernels leave it untouched.
 struct RwmStateLayout {
-    int THETA, MEAN, C, R, S, TOTAL;
+    int THETA, MEAN, C, R, S, Q, TOTAL;
 };
 __host__ __device__ constexpr RwmStateLayout rwm_state_layout(int d)
 {
-    const int T = d * (d + 1) / 2;
-    return RwmStateLayout{0, d, 2 * d, 2 * d + T, 2 * d + 2 * T, 2 * d + 2 * T + (int)kRwmStateScalars};
+    const int T = d * (d + 1) / 2, S = 2 * d + 2 * T, Q = S + (int)kRwmStateScalars;
+    return RwmStateLayout{0, d, 2 * d, 2 * d + T, S, Q, Q + 2 * d};
 }
 
 // ---- parameter-block / LDS layouts of the one-chain-per-lane kernels ---------------------------

@@ -77,6 +77,10 @@ struct BlockLayout {
     // LDS: R, theta, mean, Y of four iterations, proposal, v + zero pad, scalars, pivot rows, diag products, per-thread partial sums
     __host__ __device__ int lds_doubles() const { return T + 8 * d + kVPad + 16 + 2 * (16 * ((d + 15) / 16) + 2) + 16 + kBlockThreads; }
     static constexpr int kVPad = 64; // zeros after v: a target run may read up to TP + 7 entries past its row's last term
+    // MCMC_FACTOR_RANK1: six vectors of fx() doubles (residual, whitened residual, p, g, u, diag R; a proposal run may read
+    // up to 31 entries past d, so every vector is padded and zero-filled) and one partial sum per thread
+    __host__ __device__ int fx() const { return 16 * ((d + 15) / 16) + 32; }
+    __host__ __device__ int fast_doubles() const { return 6 * fx() + kBlockThreads; }
 };
 
 // Length of the runs block_segments (below) cuts rows c = 0..d-1 of c + extra terms into: the smallest S >= min_run
@@ -117,9 +121,12 @@ struct DppCtrl {
 };
 
 // USER: the target is mcmc_user_target_part (run-time compiled module); its parameters take the place of Hq
-template <int NT, bool FULL, bool USER>
+// FAST: MCMC_FACTOR_RANK1 -- between full factorizations every refresh_every iterations, the factor follows covmat_empirical
+// by the closed-form rank-1 update of fast_update below (not a parity mode; FULL and USER are off)
+template <int NT, bool FULL, bool USER, bool FAST = false>
 __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) void rwm_block_kernel(const RwmArgs a, const double *__restrict__ prm)
 {
+    static_assert(!FAST || (!FULL && !USER), "the rank-1 mode has no diagnostics / injected streams / user targets");
     extern __shared__ double lds[];
     const int d = a.d;
     const BlockLayout L(d);
@@ -135,7 +142,14 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
     double *const raw = sc + 16;  // two unscaled pivot rows (double buffer): 16 NT entries, the pivot, one pad
     constexpr int RS = 16 * NT + 2;
     double *const part = raw + 2 * RS + 16; // per-thread partial sums of the proposal; pivots / 1 / R_jj while R is factored
-    double *const Hl = part + kBlockThreads; // the first KL rows of Hq, [t][thread]
+    // MCMC_FACTOR_RANK1 state (FX = 0 otherwise): rres = the last residual theta - theta_mean; qv = its whitened form
+    // R^-T r with respect to the CURRENT factor; pv, gv, uv = the vectors of the update being applied; Rd = diag(R);
+    // ptot = per-thread partial sums of the update
+    const int FX = FAST ? L.fx() : 0;
+    double *const rres = part + kBlockThreads;
+    double *const qv = rres + FX, *const pv = qv + FX, *const gv = pv + FX, *const uv = gv + FX, *const Rd = uv + FX;
+    double *const ptot = Rd + FX;
+    double *const Hl = FAST ? ptot + kBlockThreads : part + kBlockThreads; // the first KL rows of Hq, [t][thread]
     constexpr int NB = NT * (NT + 1) / 2;
     const int64_t n = a.n_chains;
     // Workgroups go round-robin to the 8 XCDs, each with its own L2, and a chain writes 8 bytes of a 64-byte trace
@@ -169,6 +183,8 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
     const int p_first = (int)prm[L.ptab() + 3 * tid + 1], p_len = (int)prm[L.ptab() + 3 * tid + 2];
     const int r_first = tid < d ? (int)prm[L.pred() + 2 * tid] : 0, r_count = tid < d ? (int)prm[L.pred() + 2 * tid + 1] : 0;
     const int ti = tid >> 4, tk = tid & 15; // tile row / column: the 16 owners of a row sit in one wave
+    // FAST: the runs of a column are consecutive threads in ascending k; this thread's column ends at thread run_end - 1
+    const int run_end = (FAST && p_col >= 0) ? (int)prm[L.pred() + 2 * p_col] + (int)prm[L.pred() + 2 * p_col + 1] : 0;
 
     // covmat_empirical tile (registers) and the working copy the factorization consumes
     // At doubles as W: between factorizations it holds this thread's run of the proposal sum -- SP consecutive entries
@@ -194,9 +210,14 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
         for (int q = 0; q < 4; ++q) Y4[q * d + tid] = 0.0;
     }
     if (tid < BlockLayout::kVPad) v[d + tid] = 0.0;
+    if constexpr (FAST) {
+        for (int e = tid; e < 6 * FX; e += kBlockThreads) rres[e] = 0.0;
+        ptot[tid] = 0.0;
+    }
     for (int t = 0; t < KL; ++t) Hl[t * kBlockThreads + tid] = Hq[t * kBlockThreads + tid];
     __syncthreads();
     load_runs();
+    if (FAST && tid < d) Rd[tid] = A[tri(tid, tid)];
 
     // sum over the wavefront, every lane gets it: four DPP steps inside each row of 16 lanes (no LDS round trip, unlike
     // a shuffle), then the four row totals through scalar registers
@@ -237,6 +258,24 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
         };
         return (row_total(0) * row_total(16)) * (row_total(32) * row_total(48));
+    };
+    // inclusive prefix sum over the lanes of a wavefront: four row_shr steps inside each row of 16, then lane 15 of a row
+    // into the next row (rows 1, 3), then lane 31 into rows 2, 3
+    [[maybe_unused]] auto wave_scan = [](double x) -> double {
+        auto step = [](double y, auto ctrl, auto rmask) -> double {
+            constexpr int C = decltype(ctrl)::value, RM = decltype(rmask)::value;
+            const uint64_t b = (uint64_t)__double_as_longlong(y);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, C, RM, 0xf, false);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), C, RM, 0xf, false);
+            return y + __longlong_as_double((long long)(((uint64_t)hi << 32) | lo)); // lanes without a source add +0.0
+        };
+        x = step(x, DppCtrl<0x111>{}, DppCtrl<0xf>{}); // row_shr:1
+        x = step(x, DppCtrl<0x112>{}, DppCtrl<0xf>{}); // row_shr:2
+        x = step(x, DppCtrl<0x114>{}, DppCtrl<0xf>{}); // row_shr:4
+        x = step(x, DppCtrl<0x118>{}, DppCtrl<0xf>{}); // row_shr:8
+        x = step(x, DppCtrl<0x142>{}, DppCtrl<0xa>{}); // row_bcast:15 into rows 1 and 3
+        x = step(x, DppCtrl<0x143>{}, DppCtrl<0xc>{}); // row_bcast:31 into rows 2 and 3
+        return x;
     };
     // -0.5 (x - m)^T H (x - m); result replicated in every thread.  An iteration is a chain of latencies, not of
     // flops: a wave alone on its SIMD issues one instruction per ~11 cycles (measured with per-phase clocks at
@@ -314,6 +353,10 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
     const double prodR0 = prodR;
     bool base_emp = false; // R holds chol(covmat_empirical)
     double s_eff = 1.0;    // covmat_proposal = s_eff^2 R^T R
+    // FAST: R (the runs W, the diagonal Rd) factors the covmat_empirical the LAST shape-phase iteration proposed from, and
+    // qv holds q = R^-T r of the residual r that iteration's update_sigma used: what the rank-1 update needs
+    [[maybe_unused]] bool fast_valid = false;
+    [[maybe_unused]] int refresh_ctr = FAST ? (a.iter_offset % a.refresh_every) : 0; // (i - 1) mod refresh_every at the top of iteration i
     if (!USER && tid < d) v[tid] = th[tid] - tmean[tid];
     __syncthreads();
     double t_cur = target(th);
@@ -355,6 +398,13 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             ring[(int64_t)wd * n] = ((uint64_t)(uint32_t)sp[(int64_t)(SL.TOTAL + 2 * wd + 1) * n] << 32) |
                                     (uint64_t)(uint32_t)sp[(int64_t)(SL.TOTAL + 2 * wd) * n];
         base_emp = ss[ST_BASE * n] != 0.0;
+        if constexpr (FAST) {
+            fast_valid = ss[ST_FAST * n] != 0.0;
+            if (tid < d) {
+                rres[tid] = sp[(int64_t)(SL.Q + tid) * n];
+                qv[tid] = sp[(int64_t)(SL.Q + d + tid) * n];
+            }
+        }
         status = (int32_t)ss[ST_STATUS * n];
         n_shape = (int32_t)ss[ST_NSHAPE * n];
         dead = status != MCMC_CHAIN_OK;
@@ -365,6 +415,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
         }
         __syncthreads();
         load_runs();
+        if (FAST && tid < d) Rd[tid] = A[tri(tid, tid)];
     }
 
     // pow(adapt_size_cooling, i - adapt_size_start), fetched one iteration ahead: the adaptation opens the
@@ -398,6 +449,16 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             refactor = !dead; // covmat_proposal = scaling_sd^2 covmat_empirical (:138)
             ++n_shape;
         }
+        // FAST: a shape-phase iteration whose factor is one rank-1 step behind covmat_empirical catches up by the update
+        // instead of a factorization, unless this iteration is a refresh point (absolute iteration numbers)
+        [[maybe_unused]] const bool shape_it = refactor;
+        [[maybe_unused]] bool fast_step = false;
+        if constexpr (FAST) {
+            const bool refresh_due = ++refresh_ctr == a.refresh_every; // i % refresh_every == 0
+            if (refresh_due) refresh_ctr = 0;
+            fast_step = shape_it && fast_valid && !refresh_due;
+            refactor = shape_it && !fast_step;
+        }
         if (FULL && tid == 0) {
             if (a.d_scaling_sd) a.d_scaling_sd[(int64_t)(li - 1) * n + c] = scaling_sd;
             if (a.d_scaling_multiplier) a.d_scaling_multiplier[(int64_t)(li - 1) * n + c] = scaling_multiplier;
@@ -408,6 +469,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             if (base_emp) { // back from the shape phase: the factor of covmat again
                 __syncthreads();
                 for (int e = tid; e < T; e += kBlockThreads) A[e] = prm[L.r0() + e];
+                if (FAST && tid < d) Rd[tid] = prm[L.r0() + tri(tid, tid)];
                 __syncthreads();
                 load_runs();
                 prodR = prodR0;
@@ -415,9 +477,78 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             }
             s_eff = scaling_sd;
         }
+        if constexpr (FAST) {
+            if (fast_step) { // uniform over the workgroup
+                // covmat_empirical_{i-1} = a C_{i-2} + b r r^T (update_sigma, :43, with a = (i-2)/(i-1), b = a/(i-1)) and
+                // C_{i-2} = R^T R, so C_{i-1} = a R^T (I + p p^T) R with p = sqrt(b/a) q, q = R^-T r (qv).  The upper
+                // factor of I + p p^T is known in closed form -- diagonal sqrt(sg_{k+1} / sg_k), entry (k, j > k)
+                // p_k p_j / sqrt(sg_k sg_{k+1}), sg_k = 1 + sum_{i<k} p_i^2 -- hence
+                //     R'_kj = g_k R_kj + u_k sum_{k < i <= j} p_i R_ij,   g_k = sqrt(a sg_{k+1} / sg_k),  u_k = sqrt(a) p_k / sqrt(sg_k sg_{k+1})
+                // and  R'^-T r = q_k / (sqrt(a) sqrt(sg_k sg_{k+1})): one prefix sum over d numbers, d square roots in
+                // parallel, and per column of R a suffix sum -- no recurrence over the pivots, O(d^2) flops.
+                const double dj = di - 1.0; // the update belongs to iteration i - 1
+                const double aj = (dj - 1.0) / dj;
+                double sqa, rsqa, sqj, rsqj;
+                fm_sqrt_rsq(aj, sqa, rsqa);
+                fm_sqrt_rsq(dj, sqj, rsqj); // sqrt(b / a) = 1 / sqrt(i - 1)
+                const double qk = tid < d ? qv[tid] : 0.0;
+                const double pk = qk * rsqj, p2 = pk * pk;
+                double inc = wave_scan(p2);
+                if ((tid & 63) == 63) sc[tid >> 6] = inc; // the wave totals (waves 2, 3 hold zeros: d <= 128)
+                __syncthreads();
+                const double tot0 = sc[0], tot1 = sc[1];
+                if (tid >= 64) inc += tot0;
+                const double sg = 1.0 + (inc - p2), sg1 = 1.0 + inc;
+                double rt_unused, rs;
+                fm_sqrt_rsq(sg * sg1, rt_unused, rs);
+                if (tid < d) {
+                    const double g = sqa * sg1 * rs;
+                    gv[tid] = g;
+                    uv[tid] = sqa * pk * rs;
+                    pv[tid] = pk;
+                    qv[tid] = qk * rs * rsqa; // R'^-T r
+                    Rd[tid] *= g;             // the diagonal: R'_kk = g_k R_kk
+                }
+                {   // prod diag(R') = prod diag(R) sqrt(a)^d sqrt(sg_d)
+                    double sp = 1.0, b = sqa;
+                    for (int e = d; e > 0; e >>= 1) {
+                        if (e & 1) sp *= b;
+                        b *= b;
+                    }
+                    double st, su_unused;
+                    fm_sqrt_rsq(1.0 + (tot0 + tot1), st, su_unused);
+                    prodR = prodR * sp * st;
+                }
+                __syncthreads();
+                // this thread's run of column c: first its share of the suffix sums, then the carry of the runs above it
+                double tot = 0.0;
+                if (p_col >= 0) {
+                    const double *const pp = pv + p_first; // past the run: W is zero, pv finite (zero past d)
+#pragma unroll
+                    for (int u = 0; u < WS; ++u) tot = fma(pp[u], W[u], tot);
+                }
+                ptot[tid] = tot;
+                __syncthreads();
+                if (p_col >= 0) {
+                    double sfx = 0.0; // sum_{k < i <= c} p_i R_ic for the entry being formed
+                    for (int t = tid + 1; t < run_end; ++t) sfx += ptot[t];
+                    const double *const pp = pv + p_first, *const gp = gv + p_first, *const up = uv + p_first;
+#pragma unroll
+                    for (int u = WS - 1; u >= 0; --u) {
+                        const double w = W[u];
+                        const double nw = fma(gp[u], w, up[u] * sfx);
+                        sfx = fma(pp[u], w, sfx);
+                        W[u] = (u < p_len) ? nw : 0.0;
+                    }
+                }
+                s_eff = scaling_sd;
+            }
+        }
         if (refactor) { // uniform over the workgroup
 #pragma unroll
             for (int q = 0; q < NB; ++q) At[q] = Ct[q];
+            // FAST: the residual rides along as an extra column of the matrix being factored, which leaves R^-T r in it
+            [[maybe_unused]] double ek = (FAST && tid < d) ? rres[tid] : 0.0;
             bool ok = true;
 #pragma unroll
             for (int a0 = 0; a0 < NT; ++a0) {
@@ -437,10 +568,17 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
                             }
                         }
                     }
+                    if constexpr (FAST) {
+                        if (tid == j) row[16 * NT + 1] = ek; // entry j of the extra column, finished by the pivots before j
+                    }
                     __syncthreads();
                     const double ajj = row[16 * NT];
                     ok = ok && (ajj > 0.0);
                     const double inv = fm_rcp(ajj);
+                    if constexpr (FAST) { // e_k -= (a_jk / a_jj) e_j for k > j (the published row starts at tile column a0
+                                          // and is zero up to the pivot; what lies before 16 a0 is an older row's)
+                        if (tid >= 16 * a0 && tid < 16 * NT) ek = fma(-(row[tid] * inv), row[16 * NT + 1], ek);
+                    }
                     double ri[NT], rk[NT];
 #pragma unroll
                     for (int x = a0; x < NT; ++x) {
@@ -472,6 +610,10 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
                     fm_sqrt_rsq(part[tid], rjj, rinv);
                     A[tri(tid, tid)] = rjj;
                     part[tid] = rinv;
+                    if constexpr (FAST) {
+                        Rd[tid] = rjj;
+                        qv[tid] = ek * rinv; // R^-T r
+                    }
                 }
                 const double wp = wave_prod(rjj);
                 if ((tid & 63) == 0) sc[4 + (tid >> 6)] = wp;
@@ -502,7 +644,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
                 __syncthreads();
             }
         }
-        if (rescale || refactor) { // 1 / sqrt((2 pi)^d det(covmat_proposal)) (:56)
+        if (rescale || refactor || (FAST && fast_step)) { // 1 / sqrt((2 pi)^d det(covmat_proposal)) (:56)
             double sp = 1.0, b = s_eff;
             for (int e = d; e > 0; e >>= 1) { // s_eff^d by repeated squaring
                 if (e & 1) sp *= b;
@@ -518,7 +660,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
                 const double s2 = mul_rn(s_eff, s_eff);
                 det = 1.0;
                 for (int k = 0; k < d && det != 0.0; ++k) { // once 0 it stays 0 (every factor is finite)
-                    const double rkk = A[tri(k, k)];
+                    const double rkk = FAST ? Rd[k] : A[tri(k, k)];
                     det = mul_rn(det, mul_rn(s2, mul_rn(rkk, rkk)));
                 }
             }
@@ -624,7 +766,12 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             thin_ctr = 0;
             ++t_kept;
         }
-        if (a.d_trace && keep && tid < d) a.d_trace[(t * d + tid) * n + c] = th[tid];
+        if (a.d_trace && keep && tid < d) {
+            if (a.trace_chain_major) // [chain][t][k]: the kept row of this chain is d contiguous doubles -- whole lines from ONE workgroup
+                a.d_trace[((int64_t)c * a.n_kept + t) * d + tid] = th[tid];
+            else
+                a.d_trace[(t * d + tid) * n + c] = th[tid];
+        }
 
         // ---- acceptance rate (:188-207), replicated ------------------------------------------------------
         const double acc = accept ? 1.0 : 0.0;
@@ -651,7 +798,14 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
                 const double r = th[tid] - mk;
                 v[tid] = r;
                 mn[tid] = mk + r * inv_i;
+                if constexpr (FAST) {
+                    rres[tid] = r;
+                    // q_i = R^-T r_i for the factor this iteration proposed from: r_i = (1 - 1/(i-1)) r_{i-1} + (theta_i -
+                    // theta_{i-1}), and the accepted step is s_eff Y R, i.e. s_eff Y once whitened
+                    if (shape_it) qv[tid] = fma(1.0 - 1.0 / (di - 1.0), qv[tid], accept ? s_eff * Y[tid] : 0.0);
+                }
             }
+            if constexpr (FAST) fast_valid = shape_it && !dead;
             __syncthreads();
             const bool sig = FULL && a.d_sigma_trace && keep;
             double rv[NT], cv[NT];
@@ -707,7 +861,19 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             sp[(int64_t)(SL.THETA + tid) * n] = th[tid];
             sp[(int64_t)(SL.MEAN + tid) * n] = mn[tid];
         }
+        if constexpr (FAST) { // the factor lives in the runs; A is only kept current by the full factorizations
+            if (p_col >= 0) {
+#pragma unroll
+                for (int u = 0; u < WS; ++u)
+                    if (u < p_len) A[tri(0, p_col) + p_first + u] = W[u];
+            }
+            __syncthreads();
+        }
         for (int e = tid; e < T; e += kBlockThreads) sp[(int64_t)(SL.R + e) * n] = A[e];
+        if (tid < d) { // the last residual and its whitened form (the rank-1 mode continues from them)
+            sp[(int64_t)(SL.Q + tid) * n] = FAST ? rres[tid] : (need_moments ? v[tid] : 0.0);
+            sp[(int64_t)(SL.Q + d + tid) * n] = FAST ? qv[tid] : 0.0;
+        }
 #pragma unroll
         for (int bb = 0; bb < NT; ++bb) {
 #pragma unroll
@@ -734,6 +900,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             ss[ST_STATUS * n] = (double)status;
             ss[ST_NSHAPE * n] = (double)n_shape;
             ss[ST_WCOUNT * n] = (double)win.count;
+            ss[ST_FAST * n] = (FAST && fast_valid) ? 1.0 : 0.0;
         }
         __syncthreads(); // thread 0's last ring store is complete (the barrier drains its vector-memory counter)
         for (int wd = tid; wd < a.win_words; wd += kBlockThreads) {
@@ -791,7 +958,10 @@ int launch_rwm_block_with(const RwmArgs &a, const RwmParams &p, hipStream_t s, b
     blob[L.meta()] = TP;
     // rows of Hq in LDS: what is left of a CU's 160 KB beside the state of the chains it holds (launch bounds: 4 / 3 / 2)
     const int nt_ = (d + 15) / 16, per_cu = nt_ <= 2 ? 4 : (nt_ <= 4 ? 3 : 2);
-    const long free_doubles = (160 * 1024 / per_cu - 1024) / 8 - L.lds_doubles();
+    const bool fast = a.factor_rank1 != 0;
+    if (fast && user) return set_error(MCMC_E_UNSUPPORTED, "MCMC_FACTOR_RANK1 serves the Gaussian target only");
+    const long own_doubles = L.lds_doubles() + (fast ? L.fast_doubles() : 0);
+    const long free_doubles = (160 * 1024 / per_cu - 1024) / 8 - own_doubles;
     const int KL = (user || nt_ < 3 || nt_ > 7) ? 0 : (int)std::max(0L, std::min<long>(TP, free_doubles / kBlockThreads)) & ~3;
     blob[L.meta() + 1] = KL;
     for (int tid = 0; tid < kBlockThreads; ++tid) {
@@ -818,10 +988,10 @@ int launch_rwm_block_with(const RwmArgs &a, const RwmParams &p, hipStream_t s, b
         (void)hipFreeAsync(d_prm, s);
         return ru;
     }
-    const size_t ldsb = ((size_t)L.lds_doubles() + (size_t)KL * kBlockThreads) * sizeof(double);
+    const size_t ldsb = ((size_t)own_doubles + (size_t)KL * kBlockThreads) * sizeof(double);
     const bool full = a.d_Z || a.d_sigma_trace || a.d_accepted || a.d_log_acceptance || a.d_log_A || a.d_scaling_sd ||
                       a.d_scaling_multiplier || a.d_rate_trace;
-    hipError_t e1 = launch(full ? 1 : 0, (unsigned)a.n_chains, (unsigned)kBlockThreads, ldsb, s, a, d_prm);
+    hipError_t e1 = launch(fast ? 2 : (full ? 1 : 0), (unsigned)a.n_chains, (unsigned)kBlockThreads, ldsb, s, a, d_prm);
     hipError_t e2 = hipFreeAsync(d_prm, s);
     if (e1 != hipSuccess) return set_error(MCMC_E_HIP, "rwm_block_kernel launch failed: %s", hipGetErrorString(e1));
     if (e2 != hipSuccess) return set_error(MCMC_E_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e2));
@@ -844,8 +1014,10 @@ int launch_rwm_block(const RwmArgs &a, const RwmParams &p, hipStream_t s)
                 return hipGetLastError();
             };
             switch (nt) {
-#define MCMC_CASE(NT) \
-    case NT: return full ? go(rwm_block_kernel<NT, true, false>) : go(rwm_block_kernel<NT, false, false>);
+#define MCMC_CASE(NT)                                                                  \
+    case NT:                                                                           \
+        return full == 2 ? go(rwm_block_kernel<NT, false, false, true>)                \
+                         : (full ? go(rwm_block_kernel<NT, true, false>) : go(rwm_block_kernel<NT, false, false>));
                 MCMC_CASE(1) MCMC_CASE(2) MCMC_CASE(3) MCMC_CASE(4) MCMC_CASE(5) MCMC_CASE(6) MCMC_CASE(7) MCMC_CASE(8)
 #undef MCMC_CASE
             default: return hipErrorInvalidValue;

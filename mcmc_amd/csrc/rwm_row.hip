@@ -672,7 +672,9 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 4 : (L == 32 ? 2 : 1
 
         // ---- trace (:185): through the LDS tile, whole runs of consecutive chains per coordinate -----------------
         if (i == next_keep) { // uniform over the workgroup
-            if (a.d_trace) {
+            if (a.d_trace && a.trace_chain_major) { // [chain][t][k]: lane j writes coordinate j, d contiguous doubles per chain
+                if (live && act) a.d_trace[((int64_t)c * a.n_kept + t_kept) * d + j] = theta;
+            } else if (a.d_trace) {
                 double *const tile = stage + (t_kept & 1) * (d * CPW);
                 if (act) tile[j * CPW + cl] = theta;
                 lds_barrier();
@@ -788,7 +790,7 @@ bool rwm_row_serves(const RwmArgs &a, int target_kind)
 {
     const bool full = a.d_Z || a.d_sigma_trace || a.d_accepted || a.d_log_acceptance || a.d_log_A || a.d_scaling_sd ||
                       a.d_scaling_multiplier || a.d_rate_trace;
-    return !full && target_kind == MCMC_TARGET_GAUSSIAN_PREC && a.d >= 1 && a.d <= kMaxRowDimRwm;
+    return !full && !a.factor_rank1 && target_kind == MCMC_TARGET_GAUSSIAN_PREC && a.d >= 1 && a.d <= kMaxRowDimRwm;
 }
 
 template <int L>

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(_lib.lib, n), f"{n} is declared in include/mcmc_amd.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes SIGNATURES and the header disagree"
-    assert _lib.lib.mcmc_amd_abi_version() == 1
+    assert _lib.lib.mcmc_amd_abi_version() == 2
     assert _lib.lib.mcmc_amd_max_lane_dim() >= 10 and _lib.lib.mcmc_amd_max_dim() >= 128
 
 
