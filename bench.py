@@ -235,6 +235,12 @@ def main():
     ap.add_argument("--workload", choices=["c2", "c3", "c4", "c4s", "c5", "r32", "r64"], default="c2")
     ap.add_argument("--chains", type=int, default=None, help="chains per GPU (default: the workload's)")
     ap.add_argument("--iters", type=int, default=None, help="iterations / sweeps (default: the workload's)")
+    ap.add_argument("--fast", action="store_true",
+                    help="d > 12 Metropolis workloads: factor_update = MCMC_FACTOR_RANK1 (NOT the parity mode; closed-form rank-1 "
+                         "update of the proposal factor, full factorization every --refresh iterations)")
+    ap.add_argument("--refresh", type=int, default=64, help="refresh_every of --fast")
+    ap.add_argument("--trace-layout", choices=["soa", "chain_major"], default=None,
+                    help="default: chain_major where a chain owns a wavefront or workgroup (c4, c4s, r64), else soa")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true")
     ap.add_argument("--rehearse", action="store_true",
@@ -344,11 +350,24 @@ def main():
         cov0 = c0 * np.eye(d)
         target = mcmc_amd.Target.gaussian(np.zeros(d), H)
         init = mcmc_amd.init_normal(1, n_chains, np.zeros(d), init_sd, chain_offset=chain_offset)
-        out = {"theta_trace": torch.empty((n_iter // thin, d, n_chains), dtype=f64, device="cuda")}
+        if args.fast and d <= 12:
+            ap.error("--fast is served by the per-workgroup kernel (d > 12)")
+        layout = args.trace_layout or ("chain_major" if d > 32 else "soa")
+        if layout == "chain_major" and d <= 12:
+            ap.error("--trace-layout chain_major needs d > 12")
+        # final_theta / final_mean / final_cov are not part of the timed path (nothing below reads them); at d = 100 the
+        # [d*d][n_chains] final covariances alone would be 10.5 GB of 8-byte-per-line stores from one-chain workgroups
+        rwm_kw = dict(trace_layout=layout, final=d <= 12)
+        if args.fast:
+            rwm_kw.update(factor_update="rank1", refresh_every=args.refresh)
+            desc += f"; NON-PARITY fast mode: rank-1 factor updates, refactorization every {args.refresh} iterations"
+        desc += f"; trace layout {layout}"
+        shape = (n_chains, n_iter // thin, d) if layout == "chain_major" else (n_iter // thin, d, n_chains)
+        out = {"theta_trace": torch.empty(shape, dtype=f64, device="cuda")}
 
         def step():
             return mcmc_amd.adapt_rwm_batch(target, n_chains, init, cov0, n_iter, ass, 0.0, 0, ashs, seed=1, thin=thin,
-                                            chain_offset=chain_offset, out=out)
+                                            chain_offset=chain_offset, out=out, **rwm_kw)
         trace_key = "theta_trace"
     else:
         if wl == "c3":
@@ -402,6 +421,10 @@ def main():
     # ---- after the timed region: convergence diagnostics (one all-reduce of 3d+1 doubles for R-hat, one scalar for ESS)
     extra = {}
     status_bad = int(all_sum((res["status"] != 0).sum().item()))
+    if is_rwm and layout == "chain_major":  # the diagnostics kernels read [n_kept][d][n_chains]
+        res = dict(res)
+        res[trace_key] = res[trace_key].permute(1, 2, 0).contiguous()
+        out.clear()
     if trace_key in res:
         n_kept = res[trace_key].shape[0]
         burn = min(n_kept // 2, 2000)
@@ -462,6 +485,7 @@ def main():
         # how many proposals died in the NaN path of mvrnorm_pdf (adaptMCMC_source.cpp:56,169-175): a sample of this
         # rank's first chains re-run with per-iteration diagnostics (same seed and chain ids)
         ns = min(256, n_chains)
+        del res[trace_key]  # room for the diagnostics arrays
         dg = mcmc_amd.adapt_rwm_batch(target, ns, init[:, :ns].contiguous(), cov0, n_iter, ass, 0.0, 0, ashs, seed=1, thin=thin,
                                       chain_offset=chain_offset, trace=False, final=False, diagnostics=True)
         extra["nan_reject_fraction"] = float(torch.isnan(dg["log_acceptance"]).double().mean().item())
@@ -473,9 +497,16 @@ def main():
     if rank == 0:
         units = n_chains * n_iter  # chain-iterations (chain-sweeps) per launch per GPU
         if is_rwm:
-            flops_launch = units * rwm_flops_per_iter(d, False) + shape_iters * (d ** 3) / 3.0
+            if args.fast:
+                # what the rank-1 mode has to do: per shape-phase iteration the factor update (per entry of the triangle
+                # g w + u s and s += p w: 5 flops, 2.5 d^2) instead of d^3/3, plus one factorization per chain when the
+                # shape phase starts and one every `refresh` shape-phase iterations
+                flops_launch = (units * rwm_flops_per_iter(d, False) + shape_iters * 2.5 * d * d
+                                + (shape_iters / args.refresh + n_chains) * (d ** 3) / 3.0)
+            else:
+                flops_launch = units * rwm_flops_per_iter(d, False) + shape_iters * (d ** 3) / 3.0
             kept = n_iter // thin
-            kernel = f"rwm_pair_kernel<{d},gaussian>" if d <= 10 else ("rwm_row_kernel" if d <= 64 else "rwm_block_kernel")
+            kernel = f"rwm_pair_kernel<{d},gaussian>" if d <= 10 else ("rwm_row_kernel" if d <= 64 and not args.fast else "rwm_block_kernel")
             per_unit = {"flops_size_phase": rwm_flops_per_iter(d, False), "flops_shape_phase": rwm_flops_per_iter(d, True)}
             unit = "chain-iterations/s"
             metric = "chain-iterations/sec (adaptive RW Metropolis, whole job)"
@@ -492,7 +523,8 @@ def main():
             # HBM (16 B read + 16 B written per chain, coordinate and counted sweep, mostly absorbed by L2 / MALL)
             bytes_launch = 24.0 * d * n_chains
         achieved_tf = flops_launch / (kern_ms * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic_bytes(wl) if (n_chains, n_iter) == defaults[wl][:2] else (None, None)
+        prof_tag = wl + ("_fast" if args.fast else "")
+        traffic, traffic_src = pmc_traffic_bytes(prof_tag) if (n_chains, n_iter) == defaults[wl][:2] else (None, None)
         line = {
             "metric": metric,
             "value": units * world * steps / elapsed,
