@@ -3,6 +3,7 @@
 // Host side of the engine: argument validation (the reference has none, SURVEY.md
 // section 8b), the once-per-call shared precompute, kernel selection, and the host-pointer
 // single-chain wrappers that give the Rcpp shim the reference's own argument / return layout.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -238,9 +239,19 @@ extern "C" int mcmc_adapt_rwm_batch(const mcmc_target *target, const mcmc_rwm_co
     };
     // pow(adapt_size_cooling, i - adapt_size_start) for i = iter_offset + (0..n) (adaptMCMC_source.cpp:123), host libm
     if (cfg->adapt_size_start != 0) {
-        std::vector<double> cool((size_t)cfg->n_iterations + 1);
-        for (int i = 0; i <= cfg->n_iterations; ++i)
-            cool[i] = std::pow(cfg->adapt_size_cooling, cfg->iter_offset + i - cfg->adapt_size_start);
+        // The table stops where the power has reached its limit for good (0.99^k is exactly 0 from k = 74 100 on; a
+        // cooling of 1 never moves): the kernels clamp the index, so a call of 2^27 iterations no longer uploads 1 GB.
+        std::vector<double> cool;
+        cool.reserve(std::min<size_t>((size_t)cfg->n_iterations + 1, 1 << 17));
+        for (int i = 0; i <= cfg->n_iterations; ++i) {
+            const int k = cfg->iter_offset + i - cfg->adapt_size_start;
+            const double v = std::pow(cfg->adapt_size_cooling, k);
+            const bool settled = !cool.empty() && k > 0 && v == cool.back() &&
+                                 (v == 0.0 || std::isinf(v) || cfg->adapt_size_cooling == 1.0 || cfg->adapt_size_cooling == 0.0);
+            if (settled) break; // every later entry equals this one
+            cool.push_back(v);
+        }
+        a.cool_last = (int32_t)cool.size() - 1;
         hipError_t e = hipMallocAsync((void **)&d_cool, cool.size() * sizeof(double), s);
         if (e != hipSuccess) return release(set_error(MCMC_E_HIP, "cooling table allocation failed: %s", hipGetErrorString(e)));
         if (const int ru = upload_block(d_cool, cool.data(), cool.size(), s); ru != MCMC_OK) return release(ru);

@@ -92,7 +92,9 @@ struct RwmArgs {
     double shape_scaling_sd;   // 2.38 / sqrt(d), evaluated on the host (adaptMCMC_source.cpp:137)
     double twopi_pow_d;        // pow(2*pi, d) (adaptMCMC_source.cpp:56)
     uint64_t seed;
-    const double *d_cool_pow;  // [n_iterations+1]: pow(adapt_size_cooling, i - adapt_size_start) (:123), or nullptr
+    const double *d_cool_pow;  // [cool_last+1]: pow(adapt_size_cooling, i - adapt_size_start) (:123) for the iterations of this
+                               // launch, cut where the power has become 0 / Inf / 1 for good: index min(li, cool_last); or nullptr
+    int32_t cool_last;
     const double *d_init;
     const double *d_Z;
     const double *d_U;

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
 
     // pow(adapt_size_cooling, i - adapt_size_start), fetched one iteration ahead: the adaptation opens the
     // iteration and would otherwise wait for an L2 round trip
-    double cool_next = ass != 0 ? a.d_cool_pow[1] : 0.0;
+    double cool_next = ass != 0 ? a.d_cool_pow[min(1, a.cool_last)] : 0.0;
     int thin_ctr = i0 % a.thin; // i mod thin and the number of rows kept so far, as running counters
     int64_t t_kept = 0;
     for (int i = i0 + 1; i <= i0 + a.n_iterations; ++i) {
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
         // Only where registers are short (NT >= 7: 44 bytes of scratch gone, d = 100 +4 %); at NT = 5, 6 the recomputed
         // masks and addresses cost 5 % (measured).
         if constexpr (NT >= 7) asm volatile("" : "+v"(tid), "+v"(t_row), "+v"(p_col));
-        if (ass != 0 && li < a.n_iterations) cool_next = a.d_cool_pow[li + 1];
+        if (ass != 0 && li < a.n_iterations) cool_next = a.d_cool_pow[min(li + 1, a.cool_last)];
         // ---- adaptation of covmat_proposal (adaptMCMC_source.cpp:117-139), replicated ---------------
         bool rescale = false, refactor = false;
         if (ass != 0 && i >= ass && (ashs == 0 || mul_rn(rate, di) < (double)ashs)) {

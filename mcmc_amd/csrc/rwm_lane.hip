@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64) void rwm_lane_kernel(const RwmArgs a, const dou
         bool dirty = false, use_emp = false;
         double s2 = 0.0;
         if (ass != 0 && i >= ass && (ashs == 0 || mul_rn(rate, di) < (double)ashs)) {
-            scaling_multiplier = exp(a.d_cool_pow[li] * (rate - 0.234));
+            scaling_multiplier = exp(a.d_cool_pow[min(li, a.cool_last)] * (rate - 0.234));
             scaling_sd = mul_rn(scaling_sd, scaling_multiplier);
             scaling_sd = (a.max_scaling_sd < scaling_sd) ? a.max_scaling_sd : scaling_sd; // std::min
             s2 = mul_rn(scaling_sd, scaling_sd);

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
         const int i = i0 + li;
         // pow(adapt_size_cooling, (i+1) - adapt_size_start) for the adaptation at the end of this iteration:
         // the scalar load is issued here so that its latency is covered by the sampling step
-        const double cool = (ass != 0 && li < n_iter) ? a.d_cool_pow[li + 1] : 0.0;
+        const double cool = (ass != 0 && li < n_iter) ? a.d_cool_pow[min(li + 1, a.cool_last)] : 0.0;
         if (li > 0) {
             double Y[D];
             sync_ok = flag_wait(flags, F_DRAW, li);

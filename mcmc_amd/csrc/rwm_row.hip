@@ -522,7 +522,7 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 4 : (L == 32 ? 2 : 1
         // in ONE evaluation: odd lanes take the first argument, even lanes the second, lanes 1 and 0 of the row report.
         double e_adapt, e_hast;
         {
-            const double xa = (ass != 0 ? a.d_cool_pow[li] : 0.0) * (rate - 0.234);
+            const double xa = (ass != 0 ? a.d_cool_pow[min(li, a.cool_last)] : 0.0) * (rate - 0.234);
             const double ex = fm_exp_t((j & 1) ? xa : -0.5 * q, fm_tab<16>(FT_EXP, i));
             e_adapt = row_bcast<1>(ex);
             e_hast = row_bcast<0>(ex);

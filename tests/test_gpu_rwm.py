@@ -147,6 +147,32 @@ def test_three_acceptance_rate_modes(cuda, tag, w, win):
     assert _rel(out["theta_trace"].cpu().numpy()[:, :, 0], g[f"trace_{tag}"]) < RTOL
 
 
+@pytest.mark.parametrize("cooling", [0.5, 1.0, 0.0, 1.5])
+@pytest.mark.parametrize("d,kernel", [(3, "lane"), (3, "pair"), (20, "row"), (20, "block")])
+def test_cooling_table_is_cut_where_the_power_has_settled(cuda, oracle, cooling, d, kernel):
+    """pow(adapt_size_cooling, i - adapt_size_start) (adaptMCMC_source.cpp:123) comes from the host's libm as a table; the
+    table stops where the power is 0 (0.5^k from k = 1 075), Inf (1.5^k from k = 1 751) or 1 for good and the kernels
+    clamp the index (a 2^27-iteration call uploaded 1 GB).  A run that goes well past the cut must
+    still follow the oracle, which calls pow every iteration."""
+    import mcmc_amd
+
+    n, nc, ass = 2100, 5, 40
+    idx = np.arange(d)
+    H = np.linalg.inv(0.6 ** np.abs(idx[:, None] - idx[None, :]))
+    H = 0.5 * (H + H.T)
+    tgt = mcmc_amd.Target.gaussian(np.zeros(d), H)
+    out = mcmc_amd.adapt_rwm_batch(tgt, nc, np.full(d, 0.5), 0.2 * np.eye(d), n, ass, 0.0, 0, 0, seed=17, kernel=kernel,
+                                   adapt_size_cooling=cooling, max_scaling_sd=3.0)
+    Z, U = mcmc_amd.rwm_streams(17, nc, n, d)
+    tr = out["theta_trace"].cpu().numpy()
+    for c in (0, 4):
+        ref = oracle.adaptMCMC(oracle.gaussian_target(np.zeros(d), H), np.full(d, 0.5), 0.2 * np.eye(d), n, ass, 0.0, 0, 0,
+                               Z.cpu().numpy()[:, :, c], U.cpu().numpy()[:, c], adapt_size_cooling=cooling, max_scaling_sd=3.0,
+                               store_sigma=False)
+        assert out["acceptance_rate"].cpu().numpy()[c] == ref["acceptance_rate"]
+        assert _rel(tr[:, :, c], ref["theta_trace"]) < 3e-12  # 2 100 iterations: see test_long_run_error_growth...
+
+
 @pytest.mark.parametrize("d,win,kernel", [(3, 200, "lane"), (3, 1000, "lane"), (5, 65, "lane"), (20, 130, "block"), (4, 64, "lane")])
 def test_acceptance_window_beyond_one_word(cuda, oracle, d, win, kernel):
     """adaptMCMC_source.cpp:194-203 takes ANY window: above 64 outcomes the device keeps them in a per-chain ring
@@ -599,6 +625,36 @@ def test_row_kernel_matches_oracle_and_block_kernel(cuda, oracle, d, n, ass, ash
         assert row["acceptance_rate"].cpu().numpy()[c] == ref["acceptance_rate"]
         np.testing.assert_allclose(row["final_cov"].cpu().numpy()[:, c].reshape(d, d, order="F"), ref["sigma_empirical"][:, :, -1],
                                    rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("d,kernel", [(63, "row"), (63, "block")])
+def test_long_run_error_growth_stays_on_the_measured_law(cuda, oracle, d, kernel):
+    """the 1e-12 cases above are 500-800 iterations long.  A random walk does not contract rounding
+    differences, and the shape phase factors a covmat_empirical that is badly conditioned while it is young, so the
+    trajectory error against the oracle GROWS with the run (profiles/r3_parity_growth.txt, tools/parity_growth.py:
+    4e-15 at 250 iterations, 2e-13 at 500 -- the jump is the start of the shape phase -- 5e-13 at 1 000, 1.3e-12 at
+    2 000, 2.8e-12 at 4 000 for d = 63; flat 4e-13 at d = 100).  north_star's 1e-12 therefore holds up to ~1 500
+    iterations at d = 63; here the 2 000-iteration run must keep EVERY decision (the acceptance rate is bit-equal) and stay
+    inside twice the measured envelope."""
+    import mcmc_amd
+
+    n, nc, ass, ashs, w = 2000, 6, 25, 200, 0.05
+    rng = np.random.default_rng(2000 + d)
+    A = rng.standard_normal((d, d))
+    H = np.linalg.inv(A @ A.T / d + np.eye(d))
+    H = 0.5 * (H + H.T)
+    m = 0.3 * rng.standard_normal(d)
+    cov0 = (0.8 / d) * np.eye(d) + (0.1 / d) * np.ones((d, d))
+    init = mcmc_amd.init_normal(9, nc, m, 1.0, chain_offset=500)
+    out = mcmc_amd.adapt_rwm_batch(mcmc_amd.Target.gaussian(m, H), nc, init, cov0, n, ass, w, 0, ashs, kernel=kernel, seed=21, chain_offset=500)
+    Z, U = mcmc_amd.rwm_streams(21, nc, n, d, chain_offset=500)
+    tr, Z, U, x0 = out["theta_trace"].cpu().numpy(), Z.cpu().numpy(), U.cpu().numpy(), init.cpu().numpy()
+    assert int(out["shape_iterations"].min()) > n // 2
+    for c in range(nc):
+        ref = oracle.adaptMCMC(oracle.gaussian_target(m, H), x0[:, c], cov0, n, ass, w, 0, ashs, Z[:, :, c], U[:, c], store_sigma=False)
+        assert out["acceptance_rate"].cpu().numpy()[c] == ref["acceptance_rate"]  # weighted rate: equal only if every decision is
+        assert _rel(tr[:1000, :, c], ref["theta_trace"][:1000]) < 1e-12
+        assert _rel(tr[:, :, c], ref["theta_trace"]) < 3e-12
 
 
 def test_row_kernel_sharding_thinning_resume_and_failure(cuda):
