@@ -49,11 +49,15 @@ __device__ __forceinline__ double accept_window_push(AcceptWindow &w, bool accep
     const double rate = div_rn((double)w.count, (double)w.len);
     const int npos = (pos + 1 == window) ? 0 : pos + 1;
     if ((npos & 63) == 0) { // this word is complete, or the ring wraps: put it away and take up the next one
-        if (store) ring[(int64_t)(pos >> 6) * n] = w.bits;
-        // the next word holds outcomes only once the ring has gone round; it was stored >= 64 iterations ago by this
-        // chain's storing thread, and is read past the vector L1 (which that store did not refresh)
+        // One thread of the chain stores the finished word; ALL threads that carry the chain's scalars (the lanes of its
+        // row, the waves of its workgroup) load the next one -- which the storing thread put away the last time the ring
+        // passed it: a whole lap earlier for long windows, but only window - 64 >= 1 iterations earlier when the window
+        // has two words (65..127).  The pair is a release store / acquire load at agent scope (the load must not be
+        // served by a vector L1 line older than the store); between the two there is program order inside a wavefront
+        // (row kernel) or the iteration's barriers (per-workgroup kernel), never less than one iteration.
+        if (store) __hip_atomic_store(ring + (int64_t)(pos >> 6) * n, w.bits, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         w.bits = (w.len == window)
-                     ? __hip_atomic_load(ring + (int64_t)(npos >> 6) * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                     ? __hip_atomic_load(ring + (int64_t)(npos >> 6) * n, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
                      : 0ull;
     }
     pos = npos;

@@ -116,12 +116,23 @@ __global__ __launch_bounds__(256) void pmvnorm_kernel(int d, const double *__res
             double s = 0.0;
             for (int j = 0; j < i; ++j) s += Lc[(size_t)i * d + j] * y[j];
             const double lii = Lc[(size_t)i * d + i];
-            const double di = pnorm_std((a[i] - s) / lii), ei = pnorm_std((b[i] - s) / lii);
-            f *= ei - di;
+            // An interval that lies in the upper tail is mirrored: Phi(b) - Phi(a) with both near 1 cancels, and beyond
+            // ~8.3 sd both ARE 1 -- the width would be 0 / the draw qnorm(1) = Inf and the next coordinate Inf - Inf
+            // (ADVICE r2).  In the lower tail the probabilities are small numbers with full relative precision.
+            const double za = (a[i] - s) / lii, zb = (b[i] - s) / lii;
+            const bool up = za > 0.0;
+            const double di = up ? pnorm_std(-zb) : pnorm_std(za), ei = up ? pnorm_std(-za) : pnorm_std(zb);
+            const double width = ei - di;
+            if (!(width > 0.0)) { // a box the arithmetic cannot tell from empty: this point contributes nothing
+                f = 0.0;
+                break;
+            }
+            f *= width;
             if (i + 1 < d) {
                 if ((i & 1) == 0) philox_uniform2(key, (uint64_t)p, 0u, TAG_PMVNORM, (uint32_t)(i >> 1), ua, ub);
                 const double wv = (i & 1) ? ub : ua;
-                y[i] = qnorm_std(di + wv * (ei - di));
+                const double yy = qnorm_std(di + wv * width); // argument in (0, 1): di < ei <= 1, 0 < wv < 1
+                y[i] = up ? -yy : yy;
             }
         }
         s1 += f;
@@ -251,7 +262,8 @@ extern "C" int mcmc_pmvnorm(int32_t d, const double *h_lower, const double *h_up
     std::vector<double> blk((size_t)d * d + 2 * d, 0.0);
     for (int i = 0; i < d; ++i) {
         for (int j = 0; j <= i; ++j) blk[(size_t)i * d + j] = R[tri(j, i)]; // lower factor L = R^T, row-major
-        if (!(h_lower[i] < h_upper[i])) return set_error(MCMC_E_BAD_ARG, "need lower[%d] < upper[%d]", i, i);
+        if (!(h_lower[i] < h_upper[i])) return set_error(MCMC_E_BAD_ARG, "need lower[%d] < upper[%d]", i, i); // also refuses NaN bounds
+        if (!std::isfinite(h_mu[i])) return set_error(MCMC_E_BAD_ARG, "mu[%d] is not finite", i);
         blk[(size_t)d * d + i] = h_lower[i] - h_mu[i];
         blk[(size_t)d * d + d + i] = h_upper[i] - h_mu[i];
     }

@@ -73,6 +73,29 @@ def test_bench_two_ranks_on_one_gpu(cuda):
     assert ln["value"] > 0 and ln["chains_failed"] == 0 and ln["rhat_max"] is not None and ln["ess_per_sec"] > 0
 
 
+def test_rccl_backend_initialises_and_all_reduces_f64(cuda):
+    """The "nccl" backend of torch.distributed IS RCCL on ROCm.  A one-GPU box cannot hold two RCCL ranks (one
+    communicator per device), so this is the one-rank rehearsal of exactly the calls bench.py and diagnostics.rhat
+    issue on a node: init_process_group("nccl", device_id=...), barrier, all-reduce MAX and SUM of float64 device
+    tensors, the partial sums of mcmc_rhat_partial through it -- in a fresh process, as under a launcher
+    (tools/rccl_check.py).  The driver's 8-GPU run is then not the first time the backend executes."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_check.py")], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+    assert "rccl one-rank rehearsal OK" in p.stdout
+
+
 def test_batch_calls_return_without_waiting_for_the_stream(cuda):
     """include/mcmc_amd.h: a batch call is asynchronous on its stream -- the parameter block travels in kernel-argument
     fills, nothing queued earlier is waited for.  A long launch followed by a short one: both calls are back on the

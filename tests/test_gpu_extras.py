@@ -80,6 +80,26 @@ def test_pmvnorm_against_exact_and_scipy(cuda):
                                mcmc_amd.mvrGaussian_pdf(x, m, S) / p, rtol=1e-13)
 
 
+def test_pmvnorm_far_tail_boxes_are_finite(cuda):
+    """a box more than ~8.3 sd above the mean made Phi(upper) - Phi(lower) = 1 - 1 and qnorm(1) = Inf, and
+    the sum NaN.  Upper-tail intervals are mirrored now: small probabilities with full relative precision."""
+    import mcmc_amd
+    from scipy import stats
+
+    mu, sd = np.zeros(3), np.array([1.0, 2.0, 0.5])
+    lower, upper = np.array([9.0, 19.0, -np.inf]), np.array([np.inf, 30.0, 0.1])
+    exact = np.prod(stats.norm.sf((lower - mu) / sd) - stats.norm.sf((upper - mu) / sd))
+    p, se = mcmc_amd.pmvnorm(lower, upper, mu, np.diag(sd ** 2), n_points=1 << 14, seed=1)
+    assert 0 < exact < 1e-35 and abs(p - exact) < 1e-10 * exact, (p, exact)
+    S = np.array([[1.0, 0.6, 0.2], [0.6, 1.0, 0.3], [0.2, 0.3, 1.0]])
+    p, se = mcmc_amd.pmvnorm(np.array([8.5, 8.5, 8.5]), np.full(3, np.inf), np.zeros(3), S, n_points=1 << 18, seed=2)
+    assert np.isfinite(p) and np.isfinite(se) and 0 < p < stats.norm.sf(8.5)
+    with pytest.raises(mcmc_amd.McmcError):
+        mcmc_amd.pmvnorm(np.array([0.0, np.nan]), np.array([1.0, 1.0]), np.zeros(2), np.eye(2))
+    with pytest.raises(mcmc_amd.McmcError):
+        mcmc_amd.pmvnorm(np.zeros(2), np.ones(2), np.array([0.0, np.nan]), np.eye(2))
+
+
 @pytest.mark.parametrize("dim", [2, 3])
 def test_lattice_walkers_bit_exact(cuda, oracle, dim):
     import mcmc_amd
