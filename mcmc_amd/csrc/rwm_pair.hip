@@ -239,8 +239,8 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
     // ================================ generator ====================================================
     // Iteration i: the d normals, exp(-|Y|^2/2) and log A of iteration i (while the sampler works on
     // iteration i-1), then update_sigma / theta_mean for iteration i-1 from the theta the sampler handed
-    // back.  covmat_empirical and theta_mean live in THIS wave's registers; the sampler gets a copy through
-    // LDS only in iterations in which one of its lanes factors it (shape phase).
+    // back.  theta_mean lives in THIS wave's registers, covmat_empirical in LDS as [element][lane] (Xl): this wave
+    // updates it there, and the sampler reads it in iterations in which one of its lanes factors it (shape phase).
     if (generator) {
         const PhiloxKey key(a.seed);
         double mean[MOMENTS ? D : 1];
