@@ -192,10 +192,11 @@ struct RowVec<16> {
     template <int G>
     __device__ __forceinline__ void dot8(double &acc, const double *m) const { fmac_dot8<G>(acc, lo, m); } // terms 8 G .. 8 G + 7
     // a[k] += v_k y for every k
-    __device__ __forceinline__ void rows(double (&a)[16], double y) const { fmac_rows16(a, lo, y); }
+    template <int K>
+    __device__ __forceinline__ void rows(double (&a)[K], double y) const { fmac_rows16(a, lo, y); }
     // a[k] += v_k y for k >= 4 (P / 4): the rows of the group that holds P and all later ones
-    template <int P>
-    __device__ __forceinline__ void rows_from(double (&a)[16], double y) const
+    template <int P, int K>
+    __device__ __forceinline__ void rows_from(double (&a)[K], double y) const
     {
         if constexpr (P / 4 <= 0) fmac_rows4<0>(a, lo, y);
         if constexpr (P / 4 <= 1) fmac_rows4<1>(a, lo, y);
@@ -239,22 +240,29 @@ struct RowVec<32> {
         else
             fmac_dot8<G - 2>(acc, hi, m);
     }
-    __device__ __forceinline__ void rows(double (&a)[32], double y) const
+    // K = number of matrix rows the kernel keeps (32, or 24 when d <= 24)
+    template <int K>
+    __device__ __forceinline__ void rows(double (&a)[K], double y) const
     {
         fmac_rows16(a, lo, y);
-        fmac_rows16(a + 16, hi, y);
+        if constexpr (K == 32) {
+            fmac_rows16(a + 16, hi, y);
+        } else {
+            fmac_rows4<0>(a + 16, hi, y);
+            fmac_rows4<1>(a + 16, hi, y);
+        }
     }
-    template <int P>
-    __device__ __forceinline__ void rows_from(double (&a)[32], double y) const
+    template <int P, int K>
+    __device__ __forceinline__ void rows_from(double (&a)[K], double y) const
     {
         if constexpr (P / 4 <= 0) fmac_rows4<0>(a, lo, y);
         if constexpr (P / 4 <= 1) fmac_rows4<1>(a, lo, y);
         if constexpr (P / 4 <= 2) fmac_rows4<2>(a, lo, y);
         if constexpr (P / 4 <= 3) fmac_rows4<3>(a, lo, y);
-        if constexpr (P / 4 <= 4) fmac_rows4<0>(a + 16, hi, y);
-        if constexpr (P / 4 <= 5) fmac_rows4<1>(a + 16, hi, y);
-        if constexpr (P / 4 <= 6) fmac_rows4<2>(a + 16, hi, y);
-        if constexpr (P / 4 <= 7) fmac_rows4<3>(a + 16, hi, y);
+        if constexpr (P / 4 <= 4 && K > 16) fmac_rows4<0>(a + 16, hi, y);
+        if constexpr (P / 4 <= 5 && K > 20) fmac_rows4<1>(a + 16, hi, y);
+        if constexpr (P / 4 <= 6 && K > 24) fmac_rows4<2>(a + 16, hi, y);
+        if constexpr (P / 4 <= 7 && K > 28) fmac_rows4<3>(a + 16, hi, y);
     }
 };
 
@@ -288,21 +296,22 @@ struct RowVec<64> {
     __device__ __forceinline__ double get() const { return row_bcast<K % 16>(v[K / 16]); }
     template <int G>
     __device__ __forceinline__ void dot8(double &acc, const double *m) const { fmac_dot8<G % 2>(acc, v[G / 2], m); }
-    __device__ __forceinline__ void rows(double (&a)[64], double y) const
+    template <int K>
+    __device__ __forceinline__ void rows(double (&a)[K], double y) const
     {
         fmac_rows16(a, v[0], y);
         fmac_rows16(a + 16, v[1], y);
         fmac_rows16(a + 32, v[2], y);
-        fmac_rows16(a + 48, v[3], y);
+        if constexpr (K == 64) fmac_rows16(a + 48, v[3], y);
     }
     // a[16 B + k] += v_{16 B + k} y, k = 0..15: one block of sixteen rows
     template <int B>
     __device__ __forceinline__ void rows16(double *a16, double y) const { fmac_rows16(a16, v[B], y); }
     // rows P .. d - 1 (whole groups of four; whole blocks of sixteen are skipped once they lie past d)
-    template <int P>
-    __device__ __forceinline__ void rows_from(double (&a)[64], double y, int d) const
+    template <int P, int K>
+    __device__ __forceinline__ void rows_from(double (&a)[K], double y, int d) const
     {
-        row_unroll<0, 4>([&](auto bc) {
+        row_unroll<0, K / 16>([&](auto bc) {
             constexpr int B = decltype(bc)::value;
             if constexpr (P / 16 <= B) {
                 if (16 * B < d) { // uniform
@@ -361,9 +370,13 @@ struct RowLayout {
     static constexpr int lds_doubles(int d, int cpw) { return STAGED + cpw * csize(d) + 2 * d * cpw; }
 };
 
-template <int L, bool STATE>
+// K: the matrix rows a lane keeps of its column -- L, or 3 L / 4 for d <= 24 (L = 32) and d <= 48 (L = 64): a quarter fewer
+// registers and a quarter fewer FMAs in every dot product, update and pivot step (d = 17..31 and
+// 33..47 idled a third to a half of the work of their row)
+template <int L, int K, bool STATE>
 __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 4 : (L == 32 ? 2 : 1)) void rwm_row_kernel(const RwmArgs a, const double *__restrict__ prm)
 {
+    static_assert(K == L || (L >= 32 && K == 3 * L / 4), "K is L or three quarters of it");
     using Lay = RowLayout<L>;
     constexpr int RPW = 64 / L;
     constexpr bool CL = L == 64; // covmat_empirical in LDS
@@ -400,11 +413,11 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 4 : (L == 32 ? 2 : 1
     const double tm = lds[Lay::TMEAN + j];
     const double min_var = lds[Lay::MINVAR], prodR0 = lds[Lay::PROD0];
 
-    double Rc[L], Cc[CL ? 1 : L];
+    double Rc[K], Cc[CL ? 1 : K];
 #pragma unroll
-    for (int k = 0; k < L; ++k) Rc[k] = R0c[k * L];
+    for (int k = 0; k < K; ++k) Rc[k] = R0c[k * L];
 #pragma unroll
-    for (int k = 0; k < (CL ? 1 : L); ++k) Cc[k] = 0.0;
+    for (int k = 0; k < (CL ? 1 : K); ++k) Cc[k] = 0.0;
     // one 16-row block B of this lane's column of covmat_empirical at a time (L = 64): f(k, reference to the entry)
     auto c_block = [&](auto bc, auto &&f) {
         constexpr int B = decltype(bc)::value;
@@ -425,7 +438,7 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 4 : (L == 32 ? 2 : 1
         const double v = x - tm;
         const RowVec<L> vv(v);
         double g = 0.0;
-        row_unroll<0, L / 8>([&](auto gc) { // eight terms per block: the row of H comes from LDS eight values at a time
+        row_unroll<0, K / 8>([&](auto gc) { // eight terms per block: the row of H comes from LDS eight values at a time
             constexpr int G = decltype(gc)::value;
             double h[8];
 #pragma unroll
@@ -455,7 +468,7 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 4 : (L == 32 ? 2 : 1
             mean = sp[(int64_t)(SL.MEAN + j) * n];
         }
 #pragma unroll
-        for (int k = 0; k < L; ++k) {
+        for (int k = 0; k < K; ++k) {
             if (act && k < d) { // column j of the symmetric covmat_empirical from its packed upper triangle; of R the part k <= j
                 const double cv = sp[(int64_t)(SL.C + (k <= j ? tri(k, j) : tri(j, k))) * n];
                 if constexpr (CL) {
@@ -546,7 +559,7 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 4 : (L == 32 ? 2 : 1
         if (rescale) {
             if (base_emp) { // back from the shape phase: the factor of covmat again
 #pragma unroll
-                for (int k = 0; k < L; ++k) Rc[k] = R0c[k * L];
+                for (int k = 0; k < K; ++k) Rc[k] = R0c[k * L];
                 prodR = prodR0;
                 base_emp = false;
             }
@@ -556,19 +569,19 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 4 : (L == 32 ? 2 : 1
         // A divergent branch: the lanes of a row belong to one chain and take it together, so every cross-lane
         // operand comes from an active lane; the rows of chains that do not factor sit it out.
         if (refactor) {
-            double (&Ac)[L] = Rc;
+            double (&Ac)[K] = Rc;
             if constexpr (CL) {
 #pragma unroll
-                for (int k = 0; k < L; ++k) Ac[k] = ((k >> 4) <= mj && mj < MB) ? Cl[16 * k] : 0.0;
+                for (int k = 0; k < K; ++k) Ac[k] = ((k >> 4) <= mj && mj < MB) ? Cl[16 * k] : 0.0;
             } else {
 #pragma unroll
-                for (int k = 0; k < L; ++k) Ac[k] = Cc[k];
+                for (int k = 0; k < K; ++k) Ac[k] = Cc[k];
             }
             bool ok = true;
             double prod = 1.0;
             int jo = j; // opaque: the 2 L lane masks j > p, j == p would otherwise be hoisted out of the iteration loop
             asm volatile("" : "+v"(jo)); // into scalar registers and come back one v_readlane at a time
-            row_unroll<0, L>([&](auto pc) {
+            row_unroll<0, K>([&](auto pc) {
                 constexpr int P = decltype(pc)::value;
                 if (P < d) { // uniform
                     double piv;
@@ -587,21 +600,21 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 4 : (L == 32 ? 2 : 1
                     // finished row p of R: R_pj = a_pj / sqrt(a_pp) for j > p, the root itself at j = p, zero for j < p
                     // (lane p: a_pp / sqrt(a_pp), the root up to an ulp -- one lane mask instead of two)
                     const double rp = (jo >= P) ? Ac[P] * rinv : 0.0;
-                    if constexpr (P + 1 < L) {
+                    if constexpr (P + 1 < K) {
                         // a_ij -= R_pi R_pj for the rows i > p (only the part i <= j is ever read), in groups of four
                         // rows.  The group that holds p also meets rows i < p, where R_pi = 0 and nothing changes, and
                         // row p itself, which is overwritten with the finished row right after.
                         const RowVec<L> rv(-rp);
                         if constexpr (CL)
-                            rv.template rows_from<P + 1>(Ac, rp, d);
+                            rv.template rows_from<P + 1, K>(Ac, rp, d);
                         else
-                            rv.template rows_from<P + 1>(Ac, rp);
+                            rv.template rows_from<P + 1, K>(Ac, rp);
                     }
                     Ac[P] = rp;
                 }
             });
 #pragma unroll
-            for (int k = 0; k < L; ++k) Rc[k] = (k < d && act) ? Ac[k] : 0.0; // the padding stays zero
+            for (int k = 0; k < K; ++k) Rc[k] = (k < d && act) ? Ac[k] : 0.0; // the padding stays zero
             prodR = prod;
             base_emp = true;
             s_eff = scaling_sd;
@@ -625,14 +638,14 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 4 : (L == 32 ? 2 : 1
                 // reject everything through the NaN of :169-175)
                 double rd = 0.0;
 #pragma unroll
-                for (int k = 0; k < L; ++k) rd = (k == j) ? Rc[k] : rd;
+                for (int k = 0; k < K; ++k) rd = (k == j) ? Rc[k] : rd;
                 const RowVec<L> dv(rd);
                 const double s2 = mul_rn(s_eff, s_eff);
                 det = 1.0;
-                row_unroll<0, L>([&](auto kc) {
-                    constexpr int K = decltype(kc)::value;
-                    if (K < d) {
-                        const double rkk = dv.template get<K>();
+                row_unroll<0, K>([&](auto kc) {
+                    constexpr int KK = decltype(kc)::value;
+                    if (KK < d) {
+                        const double rkk = dv.template get<KK>();
                         det = mul_rn(det, mul_rn(s2, mul_rn(rkk, rkk)));
                     }
                 });
@@ -643,7 +656,7 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 4 : (L == 32 ? 2 : 1
         // ---- proposal theta + s (Y R) (:153-154) and |Y|^2 for the Hastings term --------------------------------
         const RowVec<L> yv(Y);
         double yr = 0.0;
-        row_unroll<0, L / 8>([&](auto gc) {
+        row_unroll<0, K / 8>([&](auto gc) {
             constexpr int G = decltype(gc)::value;
             yv.template dot8<G>(yr, Rc + 8 * G); // blocks past d multiply zeros: skipping them (uniform branches) measured slower
         });
@@ -709,7 +722,7 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 4 : (L == 32 ? 2 : 1
             mean += res * inv_i;
             const RowVec<L> bv((sfac * inv_i) * res);
             if constexpr (CL) {
-                row_unroll<0, 4>([&](auto bc) {
+                row_unroll<0, K / 16>([&](auto bc) {
                     c_block(bc, [&](double(&t)[16]) {
 #pragma unroll
                         for (int k = 0; k < 16; ++k) t[k] *= sfac;
@@ -718,8 +731,8 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 4 : (L == 32 ? 2 : 1
                 });
             } else {
 #pragma unroll
-                for (int k = 0; k < L; ++k) Cc[k] *= sfac;
-                bv.rows(Cc, res);
+                for (int k = 0; k < K; ++k) Cc[k] *= sfac;
+                bv.template rows<K>(Cc, res);
             }
         }
     }
@@ -730,7 +743,7 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 4 : (L == 32 ? 2 : 1
         if (a.d_final_cov) { // the upper triangle, mirrored: the entries k > j of a lane's column are the same numbers up to
                              // rounding ((f r_k) r_j against (f r_j) r_k) and are never read -- the factorization uses k <= j
 #pragma unroll
-            for (int k = 0; k < L; ++k) {
+            for (int k = 0; k < K; ++k) {
                 if (k <= j) {
                     const double cv = CL ? Cl[16 * k] : Cc[CL ? 0 : k];
                     a.d_final_cov[(int64_t)(j * d + k) * n + c] = cv;
@@ -750,7 +763,7 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 4 : (L == 32 ? 2 : 1
             sp[(int64_t)(SL.THETA + j) * n] = theta;
             sp[(int64_t)(SL.MEAN + j) * n] = mean;
 #pragma unroll
-            for (int k = 0; k < L; ++k) {
+            for (int k = 0; k < K; ++k) {
                 if (k <= j) {
                     sp[(int64_t)(SL.C + tri(k, j)) * n] = CL ? Cl[16 * k] : Cc[CL ? 0 : k];
                     sp[(int64_t)(SL.R + tri(k, j)) * n] = Rc[k];
@@ -793,7 +806,7 @@ bool rwm_row_serves(const RwmArgs &a, int target_kind)
     return !full && !a.factor_rank1 && target_kind == MCMC_TARGET_GAUSSIAN_PREC && a.d >= 1 && a.d <= kMaxRowDimRwm;
 }
 
-template <int L>
+template <int L, int K>
 static int launch_rwm_row_l(const RwmArgs &a, const RwmParams &p, hipStream_t s)
 {
     using Lay = RowLayout<L>;
@@ -836,7 +849,7 @@ static int launch_rwm_row_l(const RwmArgs &a, const RwmParams &p, hipStream_t s)
             hipLaunchKernelGGL(kern, dim3(grid), dim3(block), ldsb, s, a, (const double *)d_prm);
             return hipGetLastError();
         };
-        e = (a.d_state_in || a.d_state_out) ? go(rwm_row_kernel<L, true>) : go(rwm_row_kernel<L, false>);
+        e = (a.d_state_in || a.d_state_out) ? go(rwm_row_kernel<L, K, true>) : go(rwm_row_kernel<L, K, false>);
     }
     hipError_t e2 = hipFreeAsync(d_prm, s);
     if (e != hipSuccess) return set_error(MCMC_E_HIP, "rwm_row_kernel launch failed: %s", hipGetErrorString(e));
@@ -849,7 +862,11 @@ int launch_rwm_row(const RwmArgs &a, const RwmParams &p, hipStream_t s)
     if (!rwm_row_serves(a, p.target_kind))
         return set_error(MCMC_E_UNSUPPORTED, "row kernel: Gaussian target, Philox streams, no per-iteration diagnostics, d <= %d", kMaxRowDimRwm);
     if ((int)p.tparams.size() != a.d + a.d * a.d) return set_error(MCMC_E_BAD_ARG, "gaussian target needs d + d*d parameters");
-    return a.d <= 16 ? launch_rwm_row_l<16>(a, p, s) : (a.d <= 32 ? launch_rwm_row_l<32>(a, p, s) : launch_rwm_row_l<64>(a, p, s));
+    if (a.d <= 16) return launch_rwm_row_l<16, 16>(a, p, s);
+    if (a.d <= 24) return launch_rwm_row_l<32, 24>(a, p, s);
+    if (a.d <= 32) return launch_rwm_row_l<32, 32>(a, p, s);
+    if (a.d <= 48) return launch_rwm_row_l<64, 48>(a, p, s);
+    return launch_rwm_row_l<64, 64>(a, p, s);
 }
 
 } // namespace mcmc
