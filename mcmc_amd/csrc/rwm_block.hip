@@ -73,7 +73,8 @@ struct BlockLayout {
     __host__ __device__ int ptab() const { return ttab() + 2 * kBlockThreads; }
     __host__ __device__ int pred() const { return ptab() + 3 * kBlockThreads; }
     __host__ __device__ int hq() const { return pred() + 2 * d; }
-    __host__ __device__ int total(int TP) const { return hq() + TP * kBlockThreads; }
+    static constexpr int kHqPad = 8; // zero rows behind Hq: the target sum loads its coefficients in batches of up to 8, unguarded
+    __host__ __device__ int total(int TP) const { return hq() + (TP + kHqPad) * kBlockThreads; }
     // LDS: R, theta, mean, Y of four iterations, proposal, v + zero pad, scalars, pivot rows, diag products, per-thread partial sums
     __host__ __device__ int lds_doubles() const { return T + 8 * d + kVPad + 16 + 2 * (16 * ((d + 15) / 16) + 2) + 16 + kBlockThreads; }
     static constexpr int kVPad = 64; // zeros after v: a target run may read up to TP + 7 entries past its row's last term
@@ -92,6 +93,17 @@ __host__ __device__ constexpr int block_run_length(int d, int extra, int min_run
         for (int c = 0; c < d; ++c) runs += (c + extra + S - 1) / S;
         if (runs <= kBlockThreads) return S;
     }
+}
+
+// Most runs the longest column (d terms) of the proposal sum is cut into, over all d served by tile count NT
+__host__ __device__ constexpr int block_max_runs(int NT)
+{
+    int worst = 1;
+    for (int d = 16 * (NT - 1) + 1; d <= 16 * NT; ++d) {
+        const int S = block_run_length(d, 1, 4), r = (d + S - 1) / S;
+        worst = r > worst ? r : worst;
+    }
+    return worst;
 }
 
 #ifndef __HIPCC_RTC__
@@ -225,8 +237,9 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
         auto dpp_add = [](double y, auto ctrl) -> double {
             constexpr int C = decltype(ctrl)::value;
             const uint64_t b = (uint64_t)__double_as_longlong(y);
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, C, 0xf, 0xf, false);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), C, 0xf, 0xf, false);
+            // bound_ctrl: every lane has a source under these four controls, so no "old" value needs materialising
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, C, 0xf, 0xf, true);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), C, 0xf, 0xf, true);
             return y + __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
         };
         x = dpp_add(x, DppCtrl<0xB1>{});  // quad_perm [1,0,3,2]: lane ^ 1
@@ -244,8 +257,8 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
         auto dpp_mul = [](double y, auto ctrl) -> double {
             constexpr int C = decltype(ctrl)::value;
             const uint64_t b = (uint64_t)__double_as_longlong(y);
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, C, 0xf, 0xf, false);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), C, 0xf, 0xf, false);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, C, 0xf, 0xf, true);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), C, 0xf, 0xf, true);
             return y * __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
         };
         x = dpp_mul(x, DppCtrl<0xB1>{});
@@ -284,8 +297,9 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
     // (block_segments): its coefficients come coalesced from L2, eight loads in flight, the v entries from LDS at
     // constant offsets, one FMA per term; one wave reduction plus four partial sums in LDS finish the sum.
     // Precondition: a barrier since v[k] = x[k] - mean[k] (USER: x[k]) was stored by thread k for every k < d.
-    auto target = [&](const double *x) -> double {
+    auto target = [&](const double *x, auto &&mid) -> double {
         if constexpr (USER) { // every thread one part of the user's sum; x (theta or the proposal) is complete in LDS
+            mid();
 #ifdef MCMC_USER_BLOCK
             const double ws = wave_sum(::mcmc_user_target_part(x, d, Hq, tid, kBlockThreads));
             if ((tid & 63) == 0) sc[4 + (tid >> 6)] = ws;
@@ -295,18 +309,24 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             return 0.0;
 #endif
         }
+        // Every thread runs the sum, with or without a run (no exec-mask branch: a thread without one has zero coefficients
+        // and its result is dropped by the select at the end), and no load is guarded: Hq is followed by kHqPad zero rows.
+        // `mid` is work that does not depend on the sum (the Hastings term's exp / log chain): it is placed behind the
+        // first coefficient requests, so that it runs while they are on their way.
         double acc = 0.0;
-        if (t_row >= 0) {
+        {
             const double *const vp = v + t_first;
             const double *const hp = Hq + tid;
             constexpr int CH = NT <= 4 ? 4 : 8; // loads in flight; small d: short runs, and the registers decide the occupancy
+            static_assert(CH <= BlockLayout::kHqPad, "the zero rows behind Hq cover one batch of loads");
             // Coefficients KL .. KL + CH - 1 are requested from L2 first and used last; the rows before them sit in LDS
             // (the L2 round trips of this sum, TP / CH of them, were 19 % of an iteration at d = 100; measured)
             int t_l2 = 0;
             if constexpr (NT >= 3 && NT <= 7) {
                 double hl[CH];
 #pragma unroll
-                for (int u = 0; u < CH; ++u) hl[u] = (KL + u < TP) ? hp[(KL + u) * kBlockThreads] : 0.0;
+                for (int u = 0; u < CH; ++u) hl[u] = hp[(KL + u) * kBlockThreads];
+                mid();
                 const double *const hs = Hl + tid;
                 for (int t = 0; t < KL; t += 4) { // KL is a multiple of 4
                     double h[4], vv[4];
@@ -324,19 +344,26 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
 #pragma unroll
                 for (int u = 0; u < CH; ++u) acc = fma(hl[u], vv[u], acc);
                 t_l2 = KL + CH;
+            } else {
+                mid();
             }
             for (int t = t_l2; t < TP; t += CH) {
                 double h[CH], vv[CH];
 #pragma unroll
-                for (int u = 0; u < CH; ++u) h[u] = (t + u < TP) ? hp[(t + u) * kBlockThreads] : 0.0;
+                for (int u = 0; u < CH; ++u) h[u] = hp[(t + u) * kBlockThreads];
 #pragma unroll
                 for (int u = 0; u < CH; ++u) vv[u] = vp[t + u]; // past the run: zero coefficient, finite v or the zero pad
 #pragma unroll
                 for (int u = 0; u < CH; ++u) acc = fma(h[u], vv[u], acc);
             }
-            acc *= v[t_row];
+            const double vr = v[t_row < 0 ? 0 : t_row];
+            acc = (t_row >= 0) ? acc * vr : 0.0;
         }
-        if (tid < d) acc = fma(Hd[tid] * v[tid], v[tid], acc);
+        {   // the diagonal term: unguarded reads (the parameter block and the LDS behind v extend past d + 255) and a select
+            const double hd = Hd[tid], vd = v[tid];
+            const double accd = fma(hd * vd, vd, acc);
+            acc = (tid < d) ? accd : acc;
+        }
         const double ws = wave_sum(acc);
         if ((tid & 63) == 0) sc[4 + (tid >> 6)] = ws;
         __syncthreads();
@@ -359,7 +386,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
     [[maybe_unused]] int refresh_ctr = FAST ? (a.iter_offset % a.refresh_every) : 0; // (i - 1) mod refresh_every at the top of iteration i
     if (!USER && tid < d) v[tid] = th[tid] - tmean[tid];
     __syncthreads();
-    double t_cur = target(th);
+    double t_cur = target(th, [] {});
     double rate = 0.0, scaling_sd = 1.0, scaling_multiplier = 1.0;
     AcceptWindow win; // replicated in every thread, like the other scalars of the chain; thread 0 stores the ring words
     int win_pos = accept_window_pos(i0, window);
@@ -708,21 +735,43 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
         // ---- proposal theta + Y * R (:153-154): one run of consecutive k of one column per thread, then the runs
         // of a column are added in order by its thread ------------------------------------------------------------
         {
+            // every thread, with or without a run (no exec-mask branch): W is zero past the run and in threads without one
+            // (load_runs); the Y read there is some finite entry of this workgroup's LDS
+            // Eight Y entries are requested at a time: left alone the compiler reads two, waits, uses them, reads two more
+            // -- WS / 2 exposed LDS round trips per run.  The scheduling fences keep the batches apart.
             double s = 0.0;
-            if (p_col >= 0) { // W is zero past the run; the Y read there is some finite entry of this workgroup's LDS
+            {
                 const double *const yp = Y + p_first;
+                constexpr int PB = 8;
 #pragma unroll
-                for (int u = 0; u < WS; ++u) s = fma(yp[u], W[u], s);
+                for (int b0 = 0; b0 < WS; b0 += PB) {
+                    double y[PB];
+#pragma unroll
+                    for (int u = 0; u < PB; ++u) y[u] = (b0 + u < WS) ? yp[b0 + u] : 0.0;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < PB; ++u)
+                        if (b0 + u < WS) s = fma(y[u], W[b0 + u], s);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             part[tid] = s;
-            // |Y|^2 for the Hastings term
-            const double yy = (tid < d) ? Y[tid] * Y[tid] : 0.0;
+            // |Y|^2 for the Hastings term (unguarded read -- tid >= d reads what follows Y in LDS -- and a select)
+            const double yt = Y[tid];
+            const double yy = (tid < d) ? yt * yt : 0.0;
             const double ys = wave_sum(yy);
             if ((tid & 63) == 0) sc[8 + (tid >> 6)] = ys;
             __syncthreads();
             if (tid < d) { // thread k is the only one that touches theta[k], proposal[k] and writes v[k]
-                double t = part[r_first];
-                for (int q = 1; q < r_count; ++q) t += part[r_first + q];
+                // the runs of column tid, added in order: a fixed number of unguarded reads and selects (a loop with a
+                // run-time count waits for every read in turn)
+                constexpr int RMAX = block_max_runs(NT); // most runs a column can have at any d of this NT
+                double pq[RMAX];
+#pragma unroll
+                for (int q = 0; q < RMAX; ++q) pq[q] = part[min(r_first + q, kBlockThreads - 1)];
+                double t = pq[0];
+#pragma unroll
+                for (int q = 1; q < RMAX; ++q) t = (q < r_count) ? t + pq[q] : t;
                 const double p = th[tid] + s_eff * t;
                 pr[tid] = p;
                 if (!USER) v[tid] = p - tmean[tid];
@@ -733,17 +782,21 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
         __syncthreads();
 
         // ---- target and Metropolis-Hastings log ratio (:157-171) --------------------------------------
-        const double t_prop = target(pr);
+        // The Hastings term log(rootTerm exp(-q/2)) (:48-64) depends on the draws only: formed INSIDE the target sum, behind
+        // its first coefficient requests, so that its ~50 dependent instructions run while those are on their way
+        double p = 0.0;
+        const double t_prop = target(pr, [&] {
+            const double pe = rootTerm * fm_exp_t(-0.5 * q, fm_tab<16>(FT_EXP, li));
+            p = fm_log_t(pe, fm_tab<16>(FT_LOG, li));
+            p = (pe == 0.0) ? -__builtin_inf() : p; // the special cases of fm_log<true>: the NaN-reject path needs them
+            p = (pe < 0.0 || pe != pe) ? __builtin_nan("") : p;
+            p = (pe == __builtin_inf()) ? pe : p;
+        });
         double la;
         if (!isfinite(t_prop)) {
             la = -__builtin_inf();
         } else {
             la = t_prop - t_cur;
-            const double pe = rootTerm * fm_exp_t(-0.5 * q, fm_tab<16>(FT_EXP, li));
-            double p = fm_log_t(pe, fm_tab<16>(FT_LOG, li));
-            p = (pe == 0.0) ? -__builtin_inf() : p; // the special cases of fm_log<true>: the NaN-reject path needs them
-            p = (pe < 0.0 || pe != pe) ? __builtin_nan("") : p;
-            p = (pe == __builtin_inf()) ? pe : p;
             la = add_rn(la, p);
             la = add_rn(la, -p);
         }
@@ -811,14 +864,18 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             double rv[NT], cv[NT];
 #pragma unroll
             for (int x = 0; x < NT; ++x) {
-                rv[x] = (16 * x + ti < d) ? bfac * v[16 * x + ti] : 0.0;
-                cv[x] = (16 * x + tk < d) ? v[16 * x + tk] : 0.0;
+                rv[x] = bfac * v[16 * x + ti]; // no range test: v is followed by kVPad zeros (16 NT - 1 < d + 16)
+                cv[x] = v[16 * x + tk];
             }
 #pragma unroll
             for (int bb = 0; bb < NT; ++bb) {
 #pragma unroll
                 for (int aa = 0; aa <= bb; ++aa) {
-                    const double val = fma(Ct[blk(aa, bb)], sfac, rv[aa] * cv[bb]);
+                    // C sfac + (bfac r_a) r_b as ONE instruction that overwrites C: left to the compiler the product becomes
+                    // the accumulator of a v_fmac and every element is then moved back (28 v_mov_b64 per iteration at d = 100)
+                    double val = Ct[blk(aa, bb)];
+                    const double rr = rv[aa] * cv[bb];
+                    asm("v_fma_f64 %0, %0, %1, %2" : "+v"(val) : "v"(sfac), "v"(rr));
                     Ct[blk(aa, bb)] = val;
                     if (sig) {
                         const int r = 16 * aa + ti, cl = 16 * bb + tk;
