@@ -195,6 +195,9 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
     const int p_first = (int)prm[L.ptab() + 3 * tid + 1], p_len = (int)prm[L.ptab() + 3 * tid + 2];
     const int r_first = tid < d ? (int)prm[L.pred() + 2 * tid] : 0, r_count = tid < d ? (int)prm[L.pred() + 2 * tid + 1] : 0;
     const int ti = tid >> 4, tk = tid & 15; // tile row / column: the 16 owners of a row sit in one wave
+    // this thread's entry of the target mean and of diag(H), in registers: read from L2 where they are used, each was a
+    // round trip on the critical path of every iteration (the parameter block extends past d + 255: no range test)
+    const double tm_k = USER ? 0.0 : tmean[tid], hd_k = USER ? 0.0 : Hd[tid];
     // FAST: the runs of a column are consecutive threads in ascending k; this thread's column ends at thread run_end - 1
     const int run_end = (FAST && p_col >= 0) ? (int)prm[L.pred() + 2 * p_col] + (int)prm[L.pred() + 2 * p_col + 1] : 0;
 
@@ -360,8 +363,8 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             acc = (t_row >= 0) ? acc * vr : 0.0;
         }
         {   // the diagonal term: unguarded reads (the parameter block and the LDS behind v extend past d + 255) and a select
-            const double hd = Hd[tid], vd = v[tid];
-            const double accd = fma(hd * vd, vd, acc);
+            const double vd = v[tid];
+            const double accd = fma(hd_k * vd, vd, acc);
             acc = (tid < d) ? accd : acc;
         }
         const double ws = wave_sum(acc);
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
     // qv holds q = R^-T r of the residual r that iteration's update_sigma used: what the rank-1 update needs
     [[maybe_unused]] bool fast_valid = false;
     [[maybe_unused]] int refresh_ctr = FAST ? (a.iter_offset % a.refresh_every) : 0; // (i - 1) mod refresh_every at the top of iteration i
-    if (!USER && tid < d) v[tid] = th[tid] - tmean[tid];
+    if (!USER && tid < d) v[tid] = th[tid] - tm_k;
     __syncthreads();
     double t_cur = target(th, [] {});
     double rate = 0.0, scaling_sd = 1.0, scaling_multiplier = 1.0;
@@ -774,7 +777,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
                 for (int q = 1; q < RMAX; ++q) t = (q < r_count) ? t + pq[q] : t;
                 const double p = th[tid] + s_eff * t;
                 pr[tid] = p;
-                if (!USER) v[tid] = p - tmean[tid];
+                if (!USER) v[tid] = p - tm_k;
             }
         }
         const double logA = sc[12 + slot];
