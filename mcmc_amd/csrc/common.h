@@ -172,6 +172,13 @@ int user_target_param_count(const void *handle, int d);
 
 // packed upper-triangular index, r <= c
 __host__ __device__ constexpr int tri(int r, int c) { return c * (c + 1) / 2 + r; }
+// column of packed element e (the inverse of tri): folds to a constant where e is one
+__host__ __device__ constexpr int tri_col(int e)
+{
+    int c = 0;
+    while ((c + 1) * (c + 2) / 2 <= e) ++c;
+    return c;
+}
 
 // ---- chain state as a checkpoint holds it: [slot][chain] doubles ------------------------------
 // theta[d] mean[d] covmat_empirical[T] (packed upper) R[T] (packed upper factor as the kernel keeps it),

@@ -300,11 +300,28 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
                     res[k] = th[k] - mean[k];
                     mean[k] = mean[k] + res[k] * inv;
                 }
+                // in batches of up to kUB elements: all reads of a batch are requested before the first is used (left alone the
+                // compiler keeps one read ahead and waits for it T / 2 times; the sampler waits for F_C meanwhile)
+                constexpr int kUB = 14;
+                double bc[D];
 #pragma unroll
-                for (int cl = 0; cl < D; ++cl) {
-                    const double bc = bfac * res[cl];
+                for (int k = 0; k < D; ++k) bc[k] = bfac * res[k];
 #pragma unroll
-                    for (int r = 0; r <= cl; ++r) Xl[tri(r, cl) * 64] = fma(Xl[tri(r, cl) * 64], sfac, bc * res[r]);
+                for (int e0 = 0; e0 < T; e0 += kUB) {
+                    double x[kUB];
+#pragma unroll
+                    for (int u = 0; u < kUB; ++u)
+                        if (e0 + u < T) x[u] = Xl[(e0 + u) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < kUB; ++u) {
+                        if (e0 + u < T) {
+                            const int cl = tri_col(e0 + u), r = e0 + u - tri(0, cl); // constants once unrolled
+                            x[u] = fma(x[u], sfac, bc[cl] * res[r]);
+                            Xl[(e0 + u) * 64] = x[u];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 flag_set(flags, F_C, i - 1); // covmat_empirical of iteration i-1 is complete
