@@ -447,8 +447,14 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
             if (i == next_keep) {
                 if (a.d_trace && live) {
                     double *const row = a.d_trace + t_kept * D * n; // wave-uniform part of the address
+                    // the D shifts (wave-uniform LDS reads) are requested together: read where they are used, each pair was
+                    // a round trip of its own in front of its two stores
+                    double sv[D];
 #pragma unroll
-                    for (int k = 0; k < D; ++k) row[(int64_t)k * n + c] = theta[k] + shift(k);
+                    for (int k = 0; k < D; ++k) sv[k] = shift(k);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < D; ++k) row[(int64_t)k * n + c] = theta[k] + sv[k];
                 }
                 next_keep += a.thin;
                 ++t_kept;
