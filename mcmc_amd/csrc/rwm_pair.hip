@@ -65,16 +65,45 @@ struct PackedTarget<MCMC_TARGET_GAUSSIAN_PREC, D> {
     // The sampler keeps the chain state CENTRED, v = theta - m (one subtraction at the start, one addition
     // per stored value), so the target reads the state as it is: -0.5 sum_j v_j (H_jj v_j + sum_{i<j} (H_ij + H_ji) v_i)
     static constexpr bool CENTRED = true;
+    // Rows J0 .. J1-1 form a group of at most kGroup coefficients (one row at least).  The coefficients of a group -- wave-
+    // uniform LDS reads -- are all requested before the first is used, and scheduling fences keep it that way: left alone
+    // the compiler, depending on the register budget of the variant, reads one pair, waits, uses it (25 exposed LDS round
+    // trips per evaluation in the variant that has registers to spare; measured: 45.6 against 42.6 ms on C2).
+    static constexpr int kGroup = 22;
+    static constexpr int group_end(int j0)
+    {
+        int j1 = j0 + 1, cnt = j0 + 1;
+        while (j1 < D && cnt + j1 + 1 <= kGroup) {
+            cnt += j1 + 1;
+            ++j1;
+        }
+        return j1;
+    }
+    template <int J0>
+    __device__ static __forceinline__ void eval_rows(const double (&v)[D], const double *p, double &q)
+    {
+        constexpr int J1 = group_end(J0);
+        constexpr int NO = J1 * (J1 - 1) / 2 - J0 * (J0 - 1) / 2; // off-diagonal coefficients of the group: contiguous in p
+        double cd[J1 - J0], co[NO > 0 ? NO : 1];
+#pragma unroll
+        for (int j = J0; j < J1; ++j) cd[j - J0] = p[D + j];
+#pragma unroll
+        for (int e = 0; e < NO; ++e) co[e] = p[2 * D + J0 * (J0 - 1) / 2 + e];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = J0; j < J1; ++j) {
+            double g = cd[j - J0] * v[j];
+#pragma unroll
+            for (int i = 0; i < j; ++i) g += co[j * (j - 1) / 2 - J0 * (J0 - 1) / 2 + i] * v[i];
+            q += v[j] * g;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (J1 < D) eval_rows<J1>(v, p, q);
+    }
     __device__ static __forceinline__ double eval(const double (&v)[D], const double *p)
     {
         double q = 0.0;
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-            double g = p[D + j] * v[j];
-#pragma unroll
-            for (int i = 0; i < j; ++i) g += p[2 * D + j * (j - 1) / 2 + i] * v[i];
-            q += v[j] * g;
-        }
+        eval_rows<0>(v, p, q);
         return -0.5 * q;
     }
 };
@@ -193,7 +222,10 @@ __device__ __forceinline__ bool flag_wait(int *flags, int which, int value)
 
 // STATE adds checkpoint / resume (d_state_in, d_state_out, iter_offset); it is a variant of its own because
 // the extra live values cost the C2 production kernel 3 % (measured).
-template <int D, int KIND, bool MOMENTS, bool STATE>
+// WIN: the acceptance rate is the mean of the last acceptance_window (<= 64) outcomes (:194-203).  A variant of its own
+// because the window word, live but unused in the other two modes, was spilled, and its reload -- a vector-memory
+// operation behind the ten trace stores -- made every iteration wait for those stores.
+template <int D, int KIND, bool MOMENTS, bool STATE, bool WIN>
 __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmArgs a, const double *__restrict__ prm)
 {
     using Lay = PairLayout<D, KIND, MOMENTS>;
@@ -367,8 +399,8 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
     fm_sqrt_rsq(a.twopi_pow_d * (prodR * prodR), sq_unused, rootTerm);
     double t_cur = PackedTarget<KIND, D>::eval(theta, tp);
     double rate = 0.0, scaling_sd = 1.0;
-    uint64_t win_bits = 0;
-    int win_len = 0;
+    [[maybe_unused]] uint64_t win_bits = 0;
+    [[maybe_unused]] int win_len = 0;
     int32_t status = MCMC_CHAIN_OK, n_shape = 0;
     bool dead = false, sync_ok = true;
     if (state_in) { // resume: everything the loop carries from one iteration to the next
@@ -384,8 +416,10 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
         s_eff = ss[ST_SEFF * n];
         prodR = ss[ST_PRODR * n];
         rootTerm = ss[ST_ROOT * n];
-        win_bits = ((uint64_t)(uint32_t)ss[ST_WHI * n] << 32) | (uint64_t)(uint32_t)ss[ST_WLO * n];
-        win_len = (int)ss[ST_WLEN * n];
+        if constexpr (WIN) {
+            win_bits = ((uint64_t)(uint32_t)ss[ST_WHI * n] << 32) | (uint64_t)(uint32_t)ss[ST_WLO * n];
+            win_len = (int)ss[ST_WLEN * n];
+        }
         base_emp = ss[ST_BASE * n] != 0.0;
         status = (int32_t)ss[ST_STATUS * n];
         n_shape = (int32_t)ss[ST_NSHAPE * n];
@@ -413,6 +447,7 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
             for (int k = 0; k < D; ++k) Y[k] = Dl[k * 64];
             const double eq = Dl[D * 64];
             const double logA = Dl[(D + 1) * 64];
+            __builtin_amdgcn_sched_barrier(0); // no arithmetic between the reads: it would wait for them one by one
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the draws are in registers
             flag_set(flags, F_READ, li);
 
@@ -465,7 +500,7 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
             if (i == 1) {
                 rate = acc;
             } else if (w == 0) {
-                if (window == 0) {
+                if (!WIN || window == 0) { // the launcher takes the WIN = false variant whenever window == 0
                     rate = add_rn(rate, div_rn(add_rn(acc, -rate), di));
                 } else {
                     win_bits = (win_bits << 1) | (accept ? 1ull : 0ull);
@@ -589,9 +624,9 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
             ss[ST_SEFF * n] = s_eff;
             ss[ST_PRODR * n] = prodR;
             ss[ST_ROOT * n] = rootTerm;
-            ss[ST_WLO * n] = (double)(uint32_t)win_bits;
-            ss[ST_WHI * n] = (double)(uint32_t)(win_bits >> 32);
-            ss[ST_WLEN * n] = (double)win_len;
+            ss[ST_WLO * n] = WIN ? (double)(uint32_t)win_bits : 0.0;
+            ss[ST_WHI * n] = WIN ? (double)(uint32_t)(win_bits >> 32) : 0.0;
+            ss[ST_WLEN * n] = WIN ? (double)win_len : 0.0;
             ss[ST_BASE * n] = base_emp ? 1.0 : 0.0;
             ss[ST_STATUS * n] = (double)(sync_ok ? status : (MCMC_CHAIN_SYNC_LOST | ((i0 + n_iter) << 4)));
             ss[ST_NSHAPE * n] = (double)n_shape;
@@ -653,8 +688,13 @@ static int launch_rwm_pair_dk(const RwmArgs &a, const RwmParams &p, hipStream_t 
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(block), ldsb, st, aa, d_prm);
                 return hipGetLastError();
             };
-            return variant == 2 ? go(rwm_pair_kernel<D, KIND, true, true>)
-                                : (variant == 1 ? go(rwm_pair_kernel<D, KIND, true, false>) : go(rwm_pair_kernel<D, KIND, false, false>));
+            if (aa.acceptance_rate_weight == 0 && aa.acceptance_window != 0)
+                return variant == 2 ? go(rwm_pair_kernel<D, KIND, true, true, true>)
+                                    : (variant == 1 ? go(rwm_pair_kernel<D, KIND, true, false, true>)
+                                                    : go(rwm_pair_kernel<D, KIND, false, false, true>));
+            return variant == 2 ? go(rwm_pair_kernel<D, KIND, true, true, false>)
+                                : (variant == 1 ? go(rwm_pair_kernel<D, KIND, true, false, false>)
+                                                : go(rwm_pair_kernel<D, KIND, false, false, false>));
         });
 }
 

@@ -218,7 +218,7 @@ extern "C" int mcmc_target_compile(const char *source, int32_t d, int32_t n_para
         hiprtcAddNameExpression(prog, is_block ? expr_block[v].c_str() : expr_lane[v].c_str());
     }
     for (int v = 0; v < 3 && has_pair; ++v) {
-        expr_pair[v] = "mcmc::rwm_pair_kernel<" + ds + ", " + ks + ", " + (v ? "true" : "false") + ", " + (v == 2 ? "true" : "false") + ">";
+        expr_pair[v] = "mcmc::rwm_pair_kernel<" + ds + ", " + ks + ", " + (v ? "true" : "false") + ", " + (v == 2 ? "true" : "false") + ", true>"; // WIN = true: the general variant
         hiprtcAddNameExpression(prog, expr_pair[v].c_str());
     }
     hiprtcAddNameExpression(prog, expr_eval.c_str());
