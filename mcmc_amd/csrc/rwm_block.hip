@@ -551,24 +551,61 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
                 }
                 __syncthreads();
                 // this thread's run of column c: first its share of the suffix sums, then the carry of the runs above it
+                // LDS operands in batches, requested together (as in the proposal run below); threads without a run take part
+                // with W = 0 and their results are never read
+                constexpr int FB = 8;
                 double tot = 0.0;
-                if (p_col >= 0) {
+                {
                     const double *const pp = pv + p_first; // past the run: W is zero, pv finite (zero past d)
 #pragma unroll
-                    for (int u = 0; u < WS; ++u) tot = fma(pp[u], W[u], tot);
+                    for (int b0 = 0; b0 < WS; b0 += FB) {
+                        double pb[FB];
+#pragma unroll
+                        for (int u = 0; u < FB; ++u) pb[u] = (b0 + u < WS) ? pp[b0 + u] : 0.0;
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < FB; ++u)
+                            if (b0 + u < WS) tot = fma(pb[u], W[b0 + u], tot);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 ptot[tid] = tot;
                 __syncthreads();
-                if (p_col >= 0) {
-                    double sfx = 0.0; // sum_{k < i <= c} p_i R_ic for the entry being formed
-                    for (int t = tid + 1; t < run_end; ++t) sfx += ptot[t];
-                    const double *const pp = pv + p_first, *const gp = gv + p_first, *const up = uv + p_first;
+                {
+                    // sum_{k < i <= c} p_i R_ic for the entry being formed: first the totals of the runs above this one in
+                    // the column (a fixed number of unguarded reads and selects; ptot is followed by the Hq rows or nothing
+                    // past thread 255, hence the clamp)
+                    constexpr int RMAX = block_max_runs(NT);
+                    double above[RMAX];
 #pragma unroll
-                    for (int u = WS - 1; u >= 0; --u) {
-                        const double w = W[u];
-                        const double nw = fma(gp[u], w, up[u] * sfx);
-                        sfx = fma(pp[u], w, sfx);
-                        W[u] = (u < p_len) ? nw : 0.0;
+                    for (int q = 0; q < RMAX - 1; ++q) above[q] = ptot[min(tid + 1 + q, kBlockThreads - 1)];
+                    double sfx = 0.0;
+#pragma unroll
+                    for (int q = 0; q < RMAX - 1; ++q) sfx = (tid + 1 + q < run_end) ? sfx + above[q] : sfx;
+                    const double *const pp = pv + p_first, *const gp = gv + p_first, *const up = uv + p_first;
+                    constexpr int NBAT = (WS + FB - 1) / FB;
+#pragma unroll
+                    for (int bi = NBAT - 1; bi >= 0; --bi) {
+                        const int b0 = bi * FB;
+                        double pb[FB], gb[FB], ub[FB];
+#pragma unroll
+                        for (int u = 0; u < FB; ++u) {
+                            const bool in = b0 + u < WS;
+                            pb[u] = in ? pp[b0 + u] : 0.0;
+                            gb[u] = in ? gp[b0 + u] : 0.0;
+                            ub[u] = in ? up[b0 + u] : 0.0;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = FB - 1; u >= 0; --u) {
+                            if (b0 + u < WS) {
+                                const double w = W[b0 + u];
+                                const double nw = fma(gb[u], w, ub[u] * sfx);
+                                sfx = fma(pb[u], w, sfx);
+                                W[b0 + u] = (b0 + u < p_len) ? nw : 0.0;
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 s_eff = scaling_sd;
