@@ -167,12 +167,14 @@ __device__ __forceinline__ void fmac_rows4<3>(double *a, double x, double y)
         : "v"(x), "v"(y));
 }
 // x of lane K of this lane's 16-lane row
+// (bound_ctrl is set on every DPP move of this file: under their controls -- row_newbcast, quad_perm, row mirrors -- every
+// lane has a source, and with it the compiler does not materialise an "old" value per move: two v_mov_b32 each)
 template <int K>
 __device__ __forceinline__ double row_bcast(double x)
 {
     const uint64_t b = (uint64_t)__double_as_longlong(x);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, 0x150 + K, 0xf, 0xf, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), 0x150 + K, 0xf, 0xf, false);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, 0x150 + K, 0xf, 0xf, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), 0x150 + K, 0xf, 0xf, true);
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
@@ -333,8 +335,8 @@ __device__ __forceinline__ double row_sum(double x)
     auto dpp_add = [](double y, auto ctrl) -> double {
         constexpr int C = decltype(ctrl)::value;
         const uint64_t b = (uint64_t)__double_as_longlong(y);
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, C, 0xf, 0xf, false);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), C, 0xf, 0xf, false);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, C, 0xf, 0xf, true);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), C, 0xf, 0xf, true);
         return y + __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
     };
     x = dpp_add(x, RowIC<0xB1>{});  // quad_perm [1,0,3,2]: lane ^ 1
@@ -523,8 +525,8 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 4 : (L == 32 ? 2 : 1
             philox_normal2_log_t(kk, gchain, (uint32_t)i, uni ? TAG_RWM_UNIFORM : TAG_RWM_NORMAL, uni ? 0u : (uint32_t)(j >> 1), z0, z1, lg,
                                  tl, ts);
             const uint64_t zb = (uint64_t)__double_as_longlong(z1); // quad_perm [0,0,2,2]: the even neighbour's second normal
-            const uint32_t zl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)zb, 0xA0, 0xf, 0xf, false);
-            const uint32_t zh = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(zb >> 32), 0xA0, 0xf, 0xf, false);
+            const uint32_t zl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)zb, 0xA0, 0xf, 0xf, true);
+            const uint32_t zh = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(zb >> 32), 0xA0, 0xf, 0xf, true);
             const double zodd = __longlong_as_double((long long)(((uint64_t)zh << 32) | zl));
             Y = act ? ((j & 1) ? zodd : z0) : 0.0;
             logA = row_bcast<1>(lg); // A is in the open interval (0,1)

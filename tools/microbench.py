@@ -111,6 +111,13 @@ def rwm_block_shape(d, chains, iters, kernel="auto"):
           f"{fl/1e12:.2f} TF alg ({fl/78.6e12*100:.1f}% of FP64 peak)  failed {bad}")
 
 
+if __name__ == "__main__" and "wide" in sys.argv:  # the tile counts above d = 100: NT = 8
+    rwm_block(128, 2048, 100)
+    rwm_block(120, 2048, 100)
+    rwm_block_shape(128, 2048, 800)
+    rwm_block_shape(113, 2048, 800)
+
+
 if __name__ == "__main__" and "shape" in sys.argv:
     rwm_block_shape(100, 3072, 1000)
     rwm_block_shape(64, 3072, 1000)
