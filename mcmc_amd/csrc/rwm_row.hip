@@ -615,8 +615,14 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 4 : (L == 32 ? 2 : 1
                     Ac[P] = rp;
                 }
             });
+            {   // the padding stays zero.  One compare against a per-lane bound, opaque to the compiler: the K loop-invariant
+                // lane masks (k < d && act) it would otherwise hoist do not fit the scalar registers, and each came back
+                // as two v_readlane per use (160 instructions per factorization at L = 32)
+                int dj = act ? d : 0;
+                asm volatile("" : "+v"(dj));
 #pragma unroll
-            for (int k = 0; k < K; ++k) Rc[k] = (k < d && act) ? Ac[k] : 0.0; // the padding stays zero
+                for (int k = 0; k < K; ++k) Rc[k] = (k < dj) ? Ac[k] : 0.0;
+            }
             prodR = prod;
             base_emp = true;
             s_eff = scaling_sd;

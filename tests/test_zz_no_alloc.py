@@ -44,6 +44,9 @@ def _run(cuda, d, n_chains, n_sweeps, seed, no_alloc, **kw):
         "m2": cuda.full((d, n_chains), np.nan, dtype=f64, device="cuda"),
         "status": cuda.full((n_chains,), -1, dtype=cuda.int32, device="cuda"),
     }
+    import gc
+
+    gc.collect()  # tensors of earlier tests must not be collected (and returned to torch's allocator) during the call
     cuda.cuda.synchronize()
     before = cuda.cuda.memory_allocated()
     res = mcmc_amd.tmvn_gibbs_batch(n_chains, n_sweeps, mu, sigma, lower, upper, np.full(d, 0.5), seed=seed, moments=True, burn=1,
