@@ -711,7 +711,8 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
                 __syncthreads();
             }
         }
-        if (rescale || refactor || (FAST && fast_step)) { // 1 / sqrt((2 pi)^d det(covmat_proposal)) (:56)
+        // rootTerm is used by the last wave alone (it forms the Hastings term, below): only that wave keeps it up to date
+        if ((rescale || refactor || (FAST && fast_step)) && tid >= kBlockThreads - 64) { // 1 / sqrt((2 pi)^d det(covmat_proposal)) (:56)
             double sp = 1.0, b = s_eff;
             for (int e = d; e > 0; e >>= 1) { // s_eff^d by repeated squaring
                 if (e & 1) sp *= b;
@@ -824,14 +825,19 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
         // ---- target and Metropolis-Hastings log ratio (:157-171) --------------------------------------
         // The Hastings term log(rootTerm exp(-q/2)) (:48-64) depends on the draws only: formed INSIDE the target sum, behind
         // its first coefficient requests, so that its ~50 dependent instructions run while those are on their way
-        double p = 0.0;
+        // ONE wave forms it (the last: at d <= 128 it owns no coordinate) and publishes it through sc[3] under the sum's own
+        // barrier: replicated in all four waves the chain was 60 of ~690 instructions per wave-iteration.
         const double t_prop = target(pr, [&] {
-            const double pe = rootTerm * fm_exp_t(-0.5 * q, fm_tab<16>(FT_EXP, li));
-            p = fm_log_t(pe, fm_tab<16>(FT_LOG, li));
-            p = (pe == 0.0) ? -__builtin_inf() : p; // the special cases of fm_log<true>: the NaN-reject path needs them
-            p = (pe < 0.0 || pe != pe) ? __builtin_nan("") : p;
-            p = (pe == __builtin_inf()) ? pe : p;
+            if (tid >= kBlockThreads - 64) { // wave-uniform
+                const double pe = rootTerm * fm_exp_t(-0.5 * q, fm_tab<16>(FT_EXP, li));
+                double pp = fm_log_t(pe, fm_tab<16>(FT_LOG, li));
+                pp = (pe == 0.0) ? -__builtin_inf() : pp; // the special cases of fm_log<true>: the NaN-reject path needs them
+                pp = (pe < 0.0 || pe != pe) ? __builtin_nan("") : pp;
+                pp = (pe == __builtin_inf()) ? pe : pp;
+                if (tid == kBlockThreads - 64) sc[3] = pp;
+            }
         });
+        const double p = sc[3];
         double la;
         if (!isfinite(t_prop)) {
             la = -__builtin_inf();
@@ -979,6 +985,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
                 if (r <= cl && cl < d) sp[(int64_t)(SL.C + tri(r, cl)) * n] = Ct[blk(aa, bb)];
             }
         }
+        if (tid == kBlockThreads - 64) sp[(int64_t)(SL.S + ST_ROOT) * n] = rootTerm; // the wave that keeps it (see the determinant block)
         if (tid == 0) {
             double *const ss = sp + (int64_t)SL.S * n;
             ss[ST_TAG * n] = (double)MCMC_KERNEL_BLOCK;
@@ -989,7 +996,6 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             ss[ST_MULT * n] = scaling_multiplier;
             ss[ST_SEFF * n] = s_eff;
             ss[ST_PRODR * n] = prodR;
-            ss[ST_ROOT * n] = rootTerm;
             ss[ST_WLO * n] = (double)(uint32_t)win.bits;
             ss[ST_WHI * n] = (double)(uint32_t)(win.bits >> 32);
             ss[ST_WLEN * n] = (double)win.len;
