@@ -460,19 +460,41 @@ extern "C" int mcmc_rwMCMC(const mcmc_target *target, int32_t d, const double *h
 // multi-chain mechanism, one adaptMCMC call per worker process under mclapply_RNG (MCMCutilty.R:103-149), and hands
 // back per-chain matrices in the layout melt_trace (MCMCutilty.R:19-35) reads.  Chains are processed in slabs whose
 // device trace stays below kChainsSlabBytes, so the host-side result may exceed the GPU's memory.
-static constexpr size_t kChainsSlabBytes = (size_t)4 << 30;
+static constexpr size_t kChainsSlabBytes = (size_t)4 << 30; // per device buffer; there are two (sampler layout, caller's layout)
 
-// device [n_kept][d][nc] (chain fastest) -> per chain an n_kept x d column-major matrix, chain c at out + c*n_kept*d
-static void untangle_trace(const double *slab, int64_t n_kept, int d, int64_t nc, double *out)
+// device [n_kept][d][nc] (chain fastest) -> per chain an n_kept x d column-major matrix, chain c at out + c*n_kept*d:
+// for every coordinate k a transpose of the (t, c) plane, 32 x 32 tiles through LDS (both sides whole 256-byte runs).
+// Done on the DEVICE, so that one copy lands the result in the caller's buffer: the first version copied the slab to a
+// host staging vector and untangled it there on one core, which made the call 500 x the kernel time (2.2 s for the 5.2 GB
+// of 65 536 chains x 1 000 iterations at d = 10, 4 ms of them sampling; measured).
+__global__ __launch_bounds__(256) void untangle_trace_kernel(const double *__restrict__ in, double *__restrict__ out, int64_t n_kept,
+                                                             int d, int64_t nc)
 {
-    constexpr int64_t TB = 64; // blocked over (t, c) so that both sides stay in cache lines
-    for (int k = 0; k < d; ++k)
-        for (int64_t t0 = 0; t0 < n_kept; t0 += TB)
-            for (int64_t c = 0; c < nc; ++c) {
-                double *dst = out + (size_t)c * n_kept * d + (size_t)k * n_kept;
-                const int64_t t1 = t0 + TB < n_kept ? t0 + TB : n_kept;
-                for (int64_t t = t0; t < t1; ++t) dst[t] = slab[((size_t)t * d + k) * nc + c];
-            }
+    __shared__ double tile[32][33];
+    const int k = blockIdx.z;
+    const int64_t c0 = (int64_t)blockIdx.x * 32, t0 = (int64_t)blockIdx.y * 32;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5; // 32 x 8 threads, four rows each
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t t = t0 + ly + 8 * r, c = c0 + lx;
+        if (t < n_kept && c < nc) tile[ly + 8 * r][lx] = in[((size_t)t * d + k) * nc + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t c = c0 + ly + 8 * r, t = t0 + lx;
+        if (t < n_kept && c < nc) out[(size_t)c * n_kept * d + (size_t)k * n_kept + t] = tile[lx][ly + 8 * r];
+    }
+}
+static int untangle_trace(const double *d_slab, double *d_out, int64_t n_kept, int d, int64_t nc, double *h_out)
+{
+    if (n_kept <= 0 || nc <= 0) return MCMC_OK;
+    const dim3 grid((unsigned)((nc + 31) / 32), (unsigned)((n_kept + 31) / 32), (unsigned)d);
+    if (grid.y > 65535u) return set_error(MCMC_E_UNSUPPORTED, "list-of-chains entry: more than 2 097 120 kept rows per chain");
+    hipLaunchKernelGGL(untangle_trace_kernel, grid, dim3(256), 0, nullptr, d_slab, d_out, n_kept, d, nc);
+    MCMC_HIP_CHECK(hipGetLastError());
+    MCMC_HIP_CHECK(hipMemcpy(h_out, d_out, (size_t)nc * n_kept * d * sizeof(double), hipMemcpyDeviceToHost));
+    return MCMC_OK;
 }
 
 static int slab_chains(int64_t n_chains, int64_t n_kept, int d)
@@ -498,15 +520,15 @@ extern "C" int mcmc_adaptMCMC_chains(const mcmc_target *target, int32_t d, int64
     if (!std::isfinite(seedMH) || seedMH < 0) return set_error(MCMC_E_BAD_ARG, "seedMH must be a finite non-negative number");
     const int64_t n_kept = n_iterations / thin;
     const int slab = slab_chains(n_chains, h_theta_trace ? n_kept : 0, d);
-    DevBuf bInit, bT, bAcc, bSt, bCov;
-    std::vector<double> hInit, hSlab, hCov;
+    DevBuf bInit, bT, bT2, bAcc, bSt, bCov;
+    std::vector<double> hInit, hCov;
     if (init_per_chain) {
         MCMC_HIP_CHECK(bInit.alloc((size_t)slab * d * sizeof(double)));
         hInit.resize((size_t)slab * d);
     }
     if (h_theta_trace) {
         MCMC_HIP_CHECK(bT.alloc((size_t)slab * n_kept * d * sizeof(double)));
-        hSlab.resize((size_t)slab * n_kept * d);
+        MCMC_HIP_CHECK(bT2.alloc((size_t)slab * n_kept * d * sizeof(double)));
     }
     if (h_acceptance_rate) MCMC_HIP_CHECK(bAcc.alloc((size_t)slab * sizeof(double)));
     if (h_covmat_empirical) {
@@ -549,8 +571,8 @@ extern "C" int mcmc_adaptMCMC_chains(const mcmc_target *target, int32_t d, int64
         if (rc != MCMC_OK) return rc;
         MCMC_HIP_CHECK(hipDeviceSynchronize());
         if (h_theta_trace) {
-            MCMC_HIP_CHECK(hipMemcpy(hSlab.data(), bT.p, (size_t)nc * n_kept * d * sizeof(double), hipMemcpyDeviceToHost));
-            untangle_trace(hSlab.data(), n_kept, d, nc, h_theta_trace + (size_t)c0 * n_kept * d);
+            rc = untangle_trace(bT.as<double>(), bT2.as<double>(), n_kept, d, nc, h_theta_trace + (size_t)c0 * n_kept * d);
+            if (rc != MCMC_OK) return rc;
         }
         if (h_acceptance_rate)
             MCMC_HIP_CHECK(hipMemcpy(h_acceptance_rate + c0, bAcc.p, (size_t)nc * sizeof(double), hipMemcpyDeviceToHost));
@@ -575,14 +597,15 @@ extern "C" int mcmc_rtmvnorm_gibbs_chains(int32_t n, int32_t d, int64_t n_chains
     if (n_chains > 0x7fffffff) return set_error(MCMC_E_BAD_ARG, "mcmc_rtmvnorm_gibbs_chains: n_chains too large");
     const int64_t n_kept = n / thin;
     const int slab = slab_chains(n_chains, n_kept, d);
-    DevBuf bInit, bT, bSt;
-    std::vector<double> hInit, hSlab((size_t)slab * n_kept * d);
+    DevBuf bInit, bT, bT2, bSt;
+    std::vector<double> hInit;
     std::vector<int32_t> hSt(slab);
     if (init_per_chain) {
         MCMC_HIP_CHECK(bInit.alloc((size_t)slab * d * sizeof(double)));
         hInit.resize((size_t)slab * d);
     }
     MCMC_HIP_CHECK(bT.alloc((size_t)slab * n_kept * d * sizeof(double)));
+    MCMC_HIP_CHECK(bT2.alloc((size_t)slab * n_kept * d * sizeof(double)));
     MCMC_HIP_CHECK(bSt.alloc((size_t)slab * sizeof(int32_t)));
     for (int64_t c0 = 0; c0 < n_chains; c0 += slab) {
         const int64_t nc = n_chains - c0 < slab ? n_chains - c0 : slab;
@@ -613,8 +636,8 @@ extern "C" int mcmc_rtmvnorm_gibbs_chains(int32_t n, int32_t d, int64_t n_chains
         int rc = mcmc_tmvn_gibbs_batch(&cfg, &io, nullptr);
         if (rc != MCMC_OK) return rc;
         MCMC_HIP_CHECK(hipDeviceSynchronize());
-        MCMC_HIP_CHECK(hipMemcpy(hSlab.data(), bT.p, (size_t)nc * n_kept * d * sizeof(double), hipMemcpyDeviceToHost));
-        untangle_trace(hSlab.data(), n_kept, d, nc, h_trace + (size_t)c0 * n_kept * d);
+        rc = untangle_trace(bT.as<double>(), bT2.as<double>(), n_kept, d, nc, h_trace + (size_t)c0 * n_kept * d);
+        if (rc != MCMC_OK) return rc;
         if (h_status) {
             MCMC_HIP_CHECK(hipMemcpy(hSt.data(), bSt.p, (size_t)nc * sizeof(int32_t), hipMemcpyDeviceToHost));
             std::memcpy(h_status + c0, hSt.data(), (size_t)nc * sizeof(int32_t));

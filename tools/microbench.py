@@ -277,3 +277,24 @@ if __name__ == "__main__" and "mid" in sys.argv:  # the 12 < d < 64 range (VERDI
         for kern in ("auto", "block"):
             rwm_block(d, 32768 if kern != "block" else 16384, 300, kernel=kern)
             rwm_block_shape(d, 32768 if kern != "block" else 8192, 600, kernel=kern)
+
+
+def chains_host(d, nc, n):
+    """the host-pointer list-of-chains entry (what an R caller reaches): upload, launch, download, untangle -- end to end"""
+    idx = np.arange(d)
+    H = np.linalg.inv(0.9 ** np.abs(idx[:, None] - idx[None, :])); H = 0.5 * (H + H.T)
+    tgt = mcmc_amd.Target.gaussian(np.zeros(d), H)
+    rng = np.random.default_rng(1)
+    X = [2.0 * rng.standard_normal(d) for _ in range(nc)]
+    f = lambda: mcmc_amd.adaptMCMC_chains(tgt, X, np.eye(d), n, 100, 0.0, 0, 500, 100, 7.0)
+    f()
+    t0 = time.perf_counter(); out = f(); dt = time.perf_counter() - t0
+    gb = nc * n * d * 8 / 1e9
+    print(f"adaptMCMC_chains d={d} chains={nc} iters={n}: {dt*1e3:.1f} ms end to end  {nc*n/dt:.3e} chain-iter/s  ({gb:.2f} GB of trace to the host, "
+          f"{gb/dt:.1f} GB/s)")
+
+
+if __name__ == "__main__" and "chains" in sys.argv:
+    chains_host(10, 4096, 2000)
+    chains_host(10, 65536, 1000)
+    chains_host(100, 1024, 1000)
