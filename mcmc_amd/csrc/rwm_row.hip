@@ -440,12 +440,31 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 4 : (L == 32 ? 2 : 1
         const double v = x - tm;
         const RowVec<L> vv(v);
         double g = 0.0;
-        row_unroll<0, K / 8>([&](auto gc) { // eight terms per block: the row of H comes from LDS eight values at a time
-            constexpr int G = decltype(gc)::value;
-            double h[8];
+        // eight terms per block: the row of H comes from LDS eight values at a time, ONE BLOCK AHEAD of its use (the
+        // scheduling fence keeps the requests of block G + 1 in front of the FMAs of block G; read where they are used,
+        // every block was an exposed LDS round trip)
+        if constexpr (L == 16) { // 128 registers per lane: no room for a second block (measured: 36 more spills)
+            row_unroll<0, K / 8>([&](auto gc) {
+                constexpr int G = decltype(gc)::value;
+                double h1[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) h[k] = Hs[(8 * G + k) * L];
-            vv.template dot8<G>(g, h);
+                for (int k = 0; k < 8; ++k) h1[k] = Hs[(8 * G + k) * L];
+                vv.template dot8<G>(g, h1);
+            });
+            return -0.5 * row_sum<L>(v * g);
+        }
+        double h[2][8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) h[0][k] = Hs[k * L];
+        row_unroll<0, K / 8>([&](auto gc) {
+            constexpr int G = decltype(gc)::value;
+            if constexpr (G + 1 < K / 8) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) h[(G + 1) & 1][k] = Hs[(8 * (G + 1) + k) * L];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            vv.template dot8<G>(g, h[G & 1]);
+            __builtin_amdgcn_sched_barrier(0);
         });
         return -0.5 * row_sum<L>(v * g);
     };
