@@ -189,6 +189,25 @@ __device__ __forceinline__ double powi(double x)
 // accesses across the counter operations.  Every wait is bounded: if a partner never arrives (a bug, not
 // a data-dependent event) the wave gives up, raises the group's abort flag and the chain status says so.
 constexpr int kSpinLimit = 1 << 22;
+template <int V>
+struct IntC {
+    static constexpr int value = V;
+};
+// covmat_empirical goes from the generator to the sampler in kPairParts parts of whole columns (see update_part); part p
+// is the columns [pair_part_col(d, p), pair_part_col(d, p + 1)).  d >= 6: the parts end at the first columns that lie
+// behind a sixth and behind half of the T elements (d = 10: columns 4 and 7, i.e. 10 + 18 + 27 elements: the early parts
+// are small because the sampler has little to do per column there); below that one part.
+constexpr int kPairParts = 3;
+__host__ __device__ constexpr int pair_part_col(int d, int part)
+{
+    if (part <= 0) return 0;
+    if (part >= kPairParts || d < 6) return d;
+    const int den = part == 1 ? 6 : 2;
+    int cl = 0;
+    while (den * tri(0, cl) < tri(0, d)) ++cl;
+    return cl;
+}
+
 enum PairFlag { F_DRAW = 0, F_READ = 1, F_THETA = 2, F_BACKREAD = 3, F_C = 4, F_ABORT = 5 };
 
 __device__ __forceinline__ void flag_set(int *flags, int which, int value)
@@ -338,25 +357,39 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
                 double bc[D];
 #pragma unroll
                 for (int k = 0; k < D; ++k) bc[k] = bfac * res[k];
+                // In parts of whole columns, each announced by itself (F_C = kPairParts (i-1) - (kPairParts-1) + part): the
+                // sampler factors column by column and starts on the first part while this wave still updates the others
+                // (waiting for all of covmat_empirical it sat out the whole update: ~240 instructions of ONE wave per iteration)
+                auto update_part = [&](auto pc) {
+                    constexpr int PART = decltype(pc)::value;
+                    constexpr int EA = tri(0, pair_part_col(D, PART)), EB = tri(0, pair_part_col(D, PART + 1));
+                    if constexpr (EA < EB) {
+                        constexpr int NB = (EB - EA + kUB - 1) / kUB, UB = (EB - EA + NB - 1) / NB; // batches of equal size
 #pragma unroll
-                for (int e0 = 0; e0 < T; e0 += kUB) {
-                    double x[kUB];
+                        for (int e0 = EA; e0 < EB; e0 += UB) {
+                            double x[UB];
 #pragma unroll
-                    for (int u = 0; u < kUB; ++u)
-                        if (e0 + u < T) x[u] = Xl[(e0 + u) * 64];
-                    __builtin_amdgcn_sched_barrier(0);
+                            for (int u = 0; u < UB; ++u)
+                                if (e0 + u < EB) x[u] = Xl[(e0 + u) * 64];
+                            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int u = 0; u < kUB; ++u) {
-                        if (e0 + u < T) {
-                            const int cl = tri_col(e0 + u), r = e0 + u - tri(0, cl); // constants once unrolled
-                            x[u] = fma(x[u], sfac, bc[cl] * res[r]);
-                            Xl[(e0 + u) * 64] = x[u];
+                            for (int u = 0; u < UB; ++u) {
+                                if (e0 + u < EB) {
+                                    const int cl = tri_col(e0 + u), r = e0 + u - tri(0, cl); // constants once unrolled
+                                    x[u] = fma(x[u], sfac, bc[cl] * res[r]);
+                                    Xl[(e0 + u) * 64] = x[u];
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
                         }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        flag_set(flags, F_C, kPairParts * (i - 1) - (kPairParts - 1) + PART); // these columns of covmat_empirical of iteration i-1 are complete
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                flag_set(flags, F_C, i - 1); // covmat_empirical of iteration i-1 is complete
+                };
+                update_part(IntC<0>{});
+                update_part(IntC<1>{});
+                update_part(IntC<2>{});
+                static_assert(kPairParts == 3, "one update_part call per part");
             }
         }
         if (MOMENTS && live) {
@@ -478,6 +511,15 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
                 for (int k = 0; k < D; ++k) theta[k] = prop[k];
                 t_cur = t_prop;
             }
+            // ---- hand theta of iteration i to the generator (update_sigma / mean, :210-214) ---------
+            // as soon as it is decided: the generator updates covmat_empirical while this wave stores the trace row and
+            // adapts, and the factorization below waits for that update
+            if (MOMENTS) {
+                if (li > 1) sync_ok = flag_wait(flags, F_BACKREAD, li - 1) && sync_ok; // the generator has taken theta of iteration i-1
+#pragma unroll
+                for (int k = 0; k < D; ++k) Bl[k * 64] = theta[k];
+                flag_set(flags, F_THETA, li);
+            }
             // ---- trace (:185) -------------------------------------------------------------------
             if (i == next_keep) {
                 if (a.d_trace && live) {
@@ -532,14 +574,7 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
                 ++n_shape;
             }
         }
-        // ---- hand theta of iteration i to the generator (update_sigma / mean, :210-214) -------------
         const bool want_c = MOMENTS && __builtin_amdgcn_ballot_w64(refactor) != 0;
-        if (MOMENTS && li > 0) {
-            if (li > 1) sync_ok = sync_ok && flag_wait(flags, F_BACKREAD, li - 1); // the generator has taken theta of iteration i-1
-#pragma unroll
-            for (int k = 0; k < D; ++k) Bl[k * 64] = theta[k];
-            flag_set(flags, F_THETA, li);
-        }
         if (rescale) {
             if (base_emp) { // back from the shape phase: the factor of covmat again
 #pragma unroll
@@ -552,35 +587,48 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
         // ---- R = chol(covmat_empirical) for iteration i + 1 (:153) ------------------------------
         if constexpr (MOMENTS) {
             if (want_c) {
-                sync_ok = sync_ok && flag_wait(flags, F_C, li);
-                if (refactor) {
-                    bool ok = true;
-                    double prod = 1.0;
-                    double rinv[D];
-                    // covmat_empirical is read INTO the registers of the factor it replaces, all T elements requested back to
-                    // back, and factored in place.  Read where it is used -- one element, wait, use, the next element -- the
-                    // factorization spent T / 2 exposed LDS round trips (~3 400 of the ~11 900 cycles of a shape-phase
-                    // iteration, measured) on 165 FMAs.  Lanes that do not refactor are masked off and keep their factor.
+                bool ok = true;
+                double prod = 1.0;
+                double rinv[D];
+                // covmat_empirical is read INTO the registers of the factor it replaces, all elements of a part requested back
+                // to back, and factored in place.  Read where it is used -- one element, wait, use, the next element -- the
+                // factorization spent T / 2 exposed LDS round trips (~3 400 of the ~11 900 cycles of a shape-phase
+                // iteration, measured) on 165 FMAs.  Lanes that do not refactor are masked off and keep their factor.
+                // Column cl needs column cl of covmat_empirical and the finished columns before it: the first parts are
+                // factored while the generator still updates the later ones (see update_part).
+                auto factor_part = [&](auto pc) {
+                    constexpr int PART = decltype(pc)::value;
+                    constexpr int CA = pair_part_col(D, PART), CB = pair_part_col(D, PART + 1);
+                    if constexpr (CA < CB) {
+                        sync_ok = sync_ok && flag_wait(flags, F_C, kPairParts * li - (kPairParts - 1) + PART);
+                        if (refactor) {
 #pragma unroll
-                    for (int e = 0; e < T; ++e) R[e] = Xl[e * 64];
+                            for (int e = tri(0, CA); e < tri(0, CB); ++e) R[e] = Xl[e * 64];
 #pragma unroll
-                    for (int cl = 0; cl < D; ++cl) {
+                            for (int cl = CA; cl < CB; ++cl) {
 #pragma unroll
-                        for (int r = 0; r < cl; ++r) {
-                            double s = R[tri(r, cl)];
+                                for (int r = 0; r < cl; ++r) {
+                                    double s = R[tri(r, cl)];
 #pragma unroll
-                            for (int m = 0; m < r; ++m) s -= R[tri(m, r)] * R[tri(m, cl)];
-                            R[tri(r, cl)] = s * rinv[r];
+                                    for (int m = 0; m < r; ++m) s -= R[tri(m, r)] * R[tri(m, cl)];
+                                    R[tri(r, cl)] = s * rinv[r];
+                                }
+                                double ajj = R[tri(cl, cl)];
+#pragma unroll
+                                for (int m = 0; m < cl; ++m) ajj -= R[tri(m, cl)] * R[tri(m, cl)];
+                                ok = ok && (ajj > 0.0);
+                                double rjj;
+                                fm_sqrt_rsq(ajj, rjj, rinv[cl]);
+                                R[tri(cl, cl)] = rjj;
+                                prod *= rjj;
+                            }
                         }
-                        double ajj = R[tri(cl, cl)];
-#pragma unroll
-                        for (int m = 0; m < cl; ++m) ajj -= R[tri(m, cl)] * R[tri(m, cl)];
-                        ok = ok && (ajj > 0.0);
-                        double rjj;
-                        fm_sqrt_rsq(ajj, rjj, rinv[cl]);
-                        R[tri(cl, cl)] = rjj;
-                        prod *= rjj;
                     }
+                };
+                factor_part(IntC<0>{});
+                factor_part(IntC<1>{});
+                factor_part(IntC<2>{});
+                if (refactor) {
                     prodR = prod;
                     base_emp = true;
                     s_eff = scaling_sd;
