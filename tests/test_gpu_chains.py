@@ -143,3 +143,29 @@ def test_rtmvnorm_gibbs_chains_equals_batch_entry_and_oracle(cuda, oracle):
     assert chains[0]["trace"].shape == (20, d)
     for c in range(66):
         assert np.array_equal(chains[c]["trace"], tr[:, :, c])
+
+
+def test_adaptMCMC_chains_large_trace_takes_the_pipelined_download(cuda):
+    """A trace of 289 MB (above four 64 MB chunks, and no multiple of a chunk): the result reaches the caller's pageable
+    buffer through the two pinned chunks and the host copy threads (api.hip: download_pipelined) and must equal the batch
+    entry's device trace bit for bit, to the last element."""
+    import mcmc_amd
+    from mcmc_amd import _lib as L
+
+    d, nc, n = 4, 8200, 1100
+    tgt = mcmc_amd.Target.gaussian(np.zeros(d), _gauss(d, 0.5))
+    start = np.full(d, 0.5)
+    ct = tgt._c()
+    trace = np.full(nc * n * d, np.nan)
+    acc = np.empty(nc)
+    status = np.full(nc, -1, dtype=np.int32)
+    rc = L.lib.mcmc_adaptMCMC_chains(C.byref(ct), d, nc, start.ctypes.data_as(L.dp), 0,
+                                     np.ascontiguousarray(np.eye(d).ravel(order="F")).ctypes.data_as(L.dp), n, 20, 0.0, 0, 0, 50, 13.0,
+                                     0.99, 50.0, 1, trace.ctypes.data_as(L.dp), acc.ctypes.data_as(L.dp), None,
+                                     status.ctypes.data_as(L.ip))
+    assert rc == 0, L.lib.mcmc_amd_last_error()
+    assert np.all(status == 0)
+    out = mcmc_amd.adapt_rwm_batch(tgt, nc, start, np.eye(d), n, 20, 0.0, 0, 0, seed=13)
+    want = out["theta_trace"].permute(2, 1, 0).contiguous().cpu().numpy()  # [chain][k][t]: chain c's n x d matrix, column-major
+    assert np.array_equal(trace.reshape(nc, d, n), want)
+    assert np.array_equal(acc, out["acceptance_rate"].cpu().numpy())
