@@ -187,8 +187,12 @@ __device__ __forceinline__ double powi(double x)
 // Data is written with ordinary LDS stores, then the counter; LDS operations of one wave complete in
 // order, so a reader that sees the counter sees the data.  The compiler fences keep it from moving LDS
 // accesses across the counter operations.  Every wait is bounded: if a partner never arrives (a bug, not
-// a data-dependent event) the wave gives up, raises the group's abort flag and the chain status says so.
-constexpr int kSpinLimit = 1 << 22;
+// a data-dependent event) the wave gives up, raises the group's abort flag and the chain status says so.  A poll is
+// ONE LDS round trip (the abort flag is looked at every 64th time) followed by a sleep of 8 x 64 cycles: the wave a
+// poller waits for is the other wave of its own SIMD, and every poll takes issue slots and LDS cycles from it.  Measured
+// on C2 (one box, two runs each): sleep 0 / 1 / 2 / 4 / 8 / 12 / 16 -> 38.9 / 38.4 / 38.3 / 38.0 / 38.0 / 37.9 / 38.6 ms;
+// with two round trips per poll and sleep 1, as it was, 38.7.
+constexpr int kSpinLimit = 1 << 21; // polls (~0.5 s) before a wave gives up
 template <int V>
 struct IntC {
     static constexpr int value = V;
@@ -228,12 +232,12 @@ __device__ __forceinline__ bool flag_wait(int *flags, int which, int value)
     int spin = 0;
 #pragma nounroll
     while (flag_peek(flags, which) < value) {
-        if (++spin > kSpinLimit || flag_peek(flags, F_ABORT) != 0) {
+        if (++spin > kSpinLimit || ((spin & 63) == 0 && flag_peek(flags, F_ABORT) != 0)) {
             ok = false;
             flag_set(flags, F_ABORT, 1);
             break;
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(8);
     }
     asm volatile("" ::: "memory");
     return ok;
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(128 * kPairGroups) void rwm_pair_kernel(const RwmAr
                             }
                             __builtin_amdgcn_sched_barrier(0);
                         }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        // (no wait: the counter store follows the element stores of this wave through the same LDS queue)
                         flag_set(flags, F_C, kPairParts * (i - 1) - (kPairParts - 1) + PART); // these columns of covmat_empirical of iteration i-1 are complete
                     }
                 };
