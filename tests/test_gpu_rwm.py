@@ -511,7 +511,11 @@ def test_block_kernel_philox_sharding_and_failure(cuda, oracle):
 
 
 @pytest.mark.parametrize("d,ass,ashs,w,win", [(10, 30, 90, 0.0, 0), (4, 20, 60, 0.05, 0), (7, 25, 0, 0.0, 20), (3, 0, 0, 0.0, 0),
-                                              (2, 10, 40, 0.0, 0)])
+                                              (2, 10, 40, 0.0, 0),
+                                              # every way covmat_empirical is cut into parts on its way to the sampler
+                                              # (rwm_pair.hip: pair_part_col; one part below d = 6), each with a shape phase
+                                              (5, 15, 50, 0.0, 0), (6, 20, 70, 0.0, 0), (7, 20, 70, 0.0, 30), (8, 20, 80, 0.1, 0),
+                                              (9, 25, 90, 0.0, 0)])
 def test_paired_wave_kernel_matches_lane_kernel_and_oracle(cuda, oracle, d, ass, ashs, w, win):
     """The production kernel for d <= 10 (sampler + generator wavefront per 64 chains, Philox streams)
     against the one-wave kernel on the same run and against the oracle fed with the streams
@@ -529,6 +533,8 @@ def test_paired_wave_kernel_matches_lane_kernel_and_oracle(cuda, oracle, d, ass,
     cuda.cuda.synchronize()
     assert np.all(pair["status"].cpu().numpy() == 0)
     assert cuda.equal(auto["theta_trace"], pair["theta_trace"])  # auto picks the paired-wave kernel here
+    if ashs:  # most chains reached the covariance adaptation (the hand-over of covmat_empirical is exercised)
+        assert float((pair["shape_iterations"] > 20).double().mean().item()) > 0.5
     tp, tl = pair["theta_trace"].cpu().numpy(), lane["theta_trace"].cpu().numpy()
     assert _rel(tp, tl) < RTOL
     np.testing.assert_array_equal(pair["acceptance_rate"].cpu().numpy(), lane["acceptance_rate"].cpu().numpy())
