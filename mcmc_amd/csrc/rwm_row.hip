@@ -600,6 +600,7 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 4 : (L == 32 ? 2 : 1
             }
             bool ok = true;
             double prod = 1.0;
+            [[maybe_unused]] const int half_base = 4 * ((int)(threadIdx.x & 63) & 32); // ds_bpermute address of lane 0 of this lane's chain (L = 32)
             int jo = j; // opaque: the 2 L lane masks j > p, j == p would otherwise be hoisted out of the iteration loop
             asm volatile("" : "+v"(jo)); // into scalar registers and come back one v_readlane at a time
             row_unroll<0, K>([&](auto pc) {
@@ -609,6 +610,20 @@ __global__ __launch_bounds__(L == 64 ? 512 : 256, L == 16 ? 4 : (L == 32 ? 2 : 1
                     if constexpr (CL) { // one chain per wavefront: the pivot is lane p's value, through a scalar register
                         const uint64_t b = (uint64_t)__double_as_longlong(Ac[P]);
                         const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)b, P), hi = __builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), P);
+                        piv = __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+                    } else if constexpr (L == 32) {
+                        // two chains per wavefront: the pivot of this lane's chain is lane (lane & 32) + P's value, fetched
+                        // through the LDS crossbar (two ds_bpermute_b32 with the lane in the offset field): spread over
+                        // both 16-lane rows and broadcast by DPP it was four moves, two row swaps, two DPP moves and three
+                        // wait states per pivot, in a loop that is bound by instruction issue
+                        // (asm: the builtin takes the whole address in a register, and the compiler then keeps one per pivot)
+                        const uint64_t b = (uint64_t)__double_as_longlong(Ac[P]);
+                        uint32_t lo, hi;
+                        asm volatile("ds_bpermute_b32 %0, %2, %3 offset:%5\n\t"
+                                     "ds_bpermute_b32 %1, %2, %4 offset:%5\n\t"
+                                     "s_waitcnt lgkmcnt(0)"
+                                     : "=&v"(lo), "=&v"(hi)
+                                     : "v"(half_base), "v"((uint32_t)b), "v"((uint32_t)(b >> 32)), "i"(4 * P));
                         piv = __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
                     } else {
                         const RowVec<L> rowp(Ac[P]); // row p of the trailing matrix: entry j in lane j
