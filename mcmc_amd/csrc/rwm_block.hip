@@ -619,16 +619,20 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             bool ok = true;
 #pragma unroll
             for (int a0 = 0; a0 < NT; ++a0) {
-                for (int jt = 0; jt < 16; ++jt) {
+                const int jt_end = __builtin_amdgcn_readfirstlane(min(16, d - 16 * a0)); // one scalar loop bound, not a range test per pivot
+                for (int jt = 0; jt < jt_end; ++jt) {
                     const int j = 16 * a0 + jt;
-                    if (j >= d) break;
                     double *const row = raw + (j & 1) * RS;
                     if (ti == jt) { // publish row j: zero up to and including the pivot, so that readers need no range test
 #pragma unroll
                         for (int bb = a0; bb < NT; ++bb) {
                             const double val = At[blk(a0, bb)]; // entries beyond d are exactly zero
                             if (bb == a0) {
-                                if (tk == jt) row[16 * NT] = val;
+                                if (tk == jt) {
+                                    row[16 * NT] = val;
+                                    part[j] = val; // the pivot, for the square roots after the loop (by its owner: a store of
+                                                   // thread 0's own cost every wave a masked block per pivot)
+                                }
                                 row[16 * bb + tk] = (tk > jt) ? val : 0.0;
                             } else {
                                 row[16 * bb + tk] = val;
@@ -652,15 +656,14 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
                         ri[x] = row[16 * x + ti] * inv;
                         rk[x] = row[16 * x + tk];
                     }
-                    // Row j of the factor goes to its place in A UNSCALED, one entry per thread of the first waves, and
-                    // the pivot to part[j]: the square roots and the scaling by 1 / R_jj wait until all pivots are done.
+                    // Row j of the factor goes to its place in A UNSCALED, one entry per thread of the first waves (the
+                    // pivot went to part[j] with the row): the square roots and the scaling by 1 / R_jj wait until all pivots are done.
                     // (With the owners finishing their row here -- square root, NT scaled stores -- one wave ran ~60
                     // instructions more than the others at every pivot, and the barrier waited for it: 32 % of a
                     // shape-phase run at d = 100, measured.)
                     {
                         const int kk = 16 * a0 + tid;
                         if (tid < 16 * (NT - a0) && kk > j && kk < d) A[tri(j, kk)] = row[kk];
-                        if (tid == 0) part[j] = ajj;
                     }
 #pragma unroll
                     for (int bb = a0; bb < NT; ++bb) {
