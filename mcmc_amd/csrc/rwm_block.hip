@@ -643,8 +643,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
                         if (tid == j) row[16 * NT + 1] = ek; // entry j of the extra column, finished by the pivots before j
                     }
                     __syncthreads();
-                    const double ajj = row[16 * NT];
-                    ok = ok && (ajj > 0.0);
+                    const double ajj = row[16 * NT]; // (whether it is positive is looked at once, after the loop, in part[])
                     const double inv = fm_rcp(ajj);
                     if constexpr (FAST) { // e_k -= (a_jk / a_jj) e_j for k > j (the published row starts at tile column a0
                                           // and is zero up to the pivot; what lies before 16 a0 is an older row's)
@@ -674,10 +673,16 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             }
             __syncthreads();
             {   // R_jj = sqrt(pivot_j), all rows at once; part[j] becomes 1 / R_jj
+                // arma::chol fails on the first pivot that is not positive (:153): every pivot is in part[] (one that is
+                // zero, negative or NaN leaves garbage behind it, but stays there itself), tested here once instead of
+                // two instructions per pivot in every wave; the verdict travels with the diagonal product
                 double rjj = 1.0;
+                const double pvt = tid < d ? part[tid] : 1.0;
+                const bool wave_bad = __builtin_amdgcn_ballot_w64(!(pvt > 0.0)) != 0;
+                if ((tid & 63) == 0) sc[8 + (tid >> 6)] = wave_bad ? 1.0 : 0.0; // (the |Y|^2 slots: free until the proposal)
                 if (tid < d) {
                     double rinv;
-                    fm_sqrt_rsq(part[tid], rjj, rinv);
+                    fm_sqrt_rsq(pvt, rjj, rinv);
                     A[tri(tid, tid)] = rjj;
                     part[tid] = rinv;
                     if constexpr (FAST) {
@@ -690,6 +695,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             }
             __syncthreads();
             prodR = (sc[4] * sc[5]) * (sc[6] * sc[7]);
+            ok = (sc[8] + sc[9]) + (sc[10] + sc[11]) == 0.0;
             // scale the rows; every thread takes the run of its proposal sum and keeps it in registers (W)
 #pragma unroll
             for (int u = 0; u < WN; ++u) {
