@@ -643,27 +643,31 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
                         if (tid == j) row[16 * NT + 1] = ek; // entry j of the extra column, finished by the pivots before j
                     }
                     __syncthreads();
+                    // everything this pivot reads is requested here, together (left alone the compiler waits for the pivot,
+                    // forms its reciprocal and only then requests the row, a pair at a time: four exposed LDS round trips)
                     const double ajj = row[16 * NT]; // (whether it is positive is looked at once, after the loop, in part[])
+                    double ri[NT], rk[NT];
+#pragma unroll
+                    for (int x = a0; x < NT; ++x) {
+                        ri[x] = row[16 * x + ti];
+                        rk[x] = row[16 * x + tk];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                     const double inv = fm_rcp(ajj);
                     if constexpr (FAST) { // e_k -= (a_jk / a_jj) e_j for k > j (the published row starts at tile column a0
                                           // and is zero up to the pivot; what lies before 16 a0 is an older row's)
                         if (tid >= 16 * a0 && tid < 16 * NT) ek = fma(-(row[tid] * inv), row[16 * NT + 1], ek);
                     }
-                    double ri[NT], rk[NT];
 #pragma unroll
-                    for (int x = a0; x < NT; ++x) {
-                        ri[x] = row[16 * x + ti] * inv;
-                        rk[x] = row[16 * x + tk];
-                    }
-                    // Row j of the factor goes to its place in A UNSCALED, one entry per thread of the first waves (the
-                    // pivot went to part[j] with the row): the square roots and the scaling by 1 / R_jj wait until all pivots are done.
+                    for (int x = a0; x < NT; ++x) ri[x] *= inv;
+                    // Nothing else happens to row j here: it stays in the registers of its owners -- the published row is zero
+                    // up to and including the pivot, so for the finished rows ri is exactly 0 and the updates below leave
+                    // them as they are -- and goes to its place in A after the loop, scaled, with all the other rows
+                    // (copied out here, one entry per thread of the first waves, it was a masked block with an LDS round
+                    // trip per pivot: ~10 of ~90 instructions).  The square roots wait until all pivots are done too.
                     // (With the owners finishing their row here -- square root, NT scaled stores -- one wave ran ~60
                     // instructions more than the others at every pivot, and the barrier waited for it: 32 % of a
                     // shape-phase run at d = 100, measured.)
-                    {
-                        const int kk = 16 * a0 + tid;
-                        if (tid < 16 * (NT - a0) && kk > j && kk < d) A[tri(j, kk)] = row[kk];
-                    }
 #pragma unroll
                     for (int bb = a0; bb < NT; ++bb) {
 #pragma unroll
@@ -696,20 +700,22 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             __syncthreads();
             prodR = (sc[4] * sc[5]) * (sc[6] * sc[7]);
             ok = (sc[8] + sc[9]) + (sc[10] + sc[11]) == 0.0;
-            // scale the rows; every thread takes the run of its proposal sum and keeps it in registers (W)
+            // the rows of the factor, R_rc = (unscaled entry) / R_rr, from the registers of the tile layout to their places in A
+            {
+                double rinv[NT];
 #pragma unroll
-            for (int u = 0; u < WN; ++u) {
-                double val = 0.0;
-                if (p_col >= 0 && u < p_len) {
-                    double *const e = A + tri(0, p_col) + p_first + u;
-                    val = *e;
-                    if (p_first + u != p_col) { // the diagonal entry is finished
-                        val *= part[p_first + u];
-                        *e = val;
+                for (int aa = 0; aa < NT; ++aa) rinv[aa] = part[16 * aa + ti]; // 1 / R_rr of this thread's rows (16 NT <= 256 entries)
+#pragma unroll
+                for (int bb = 0; bb < NT; ++bb) {
+#pragma unroll
+                    for (int aa = 0; aa <= bb; ++aa) {
+                        const int r = 16 * aa + ti, cl = 16 * bb + tk;
+                        if (r < cl && cl < d) A[tri(r, cl)] = At[blk(aa, bb)] * rinv[aa];
                     }
                 }
-                W[u] = val;
             }
+            __syncthreads();
+            load_runs(); // every thread takes the run of its proposal sum and keeps it in registers (W)
             __syncthreads();
             base_emp = true;
             s_eff = scaling_sd;
