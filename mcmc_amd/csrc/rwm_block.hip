@@ -620,9 +620,16 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
 #pragma unroll
             for (int a0 = 0; a0 < NT; ++a0) {
                 const int jt_end = __builtin_amdgcn_readfirstlane(min(16, d - 16 * a0)); // one scalar loop bound, not a range test per pivot
-                for (int jt = 0; jt < jt_end; ++jt) {
+                // two pivots per turn of the loop, so that WHICH of the two row buffers a pivot uses is known at compile time
+                // and lands in the offset fields of its LDS instructions (selected per pivot it was three scalar and four
+                // vector instructions of address arithmetic in every wave)
+                for (int jt0 = 0; jt0 < jt_end; jt0 += 2) {
+#pragma unroll
+                  for (int par = 0; par < 2; ++par) {
+                    const int jt = jt0 + par;
+                    if (par == 1 && jt >= jt_end) break; // uniform
                     const int j = 16 * a0 + jt;
-                    double *const row = raw + (j & 1) * RS;
+                    double *const row = raw + par * RS; // j & 1 == par: 16 a0 and jt0 are even
                     if (ti == jt) { // publish row j: zero up to and including the pivot, so that readers need no range test
 #pragma unroll
                         for (int bb = a0; bb < NT; ++bb) {
@@ -673,6 +680,7 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
 #pragma unroll
                         for (int aa = a0; aa <= bb; ++aa) At[blk(aa, bb)] = fma(-ri[aa], rk[bb], At[blk(aa, bb)]);
                     }
+                  }
                 }
             }
             __syncthreads();
