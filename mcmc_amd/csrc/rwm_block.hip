@@ -617,6 +617,12 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
             // FAST: the residual rides along as an extra column of the matrix being factored, which leaves R^-T r in it
             [[maybe_unused]] double ek = (FAST && tid < d) ? rres[tid] : 0.0;
             bool ok = true;
+            // this thread's two windows into the row buffers, as bases of their own (opaque: merged with a neighbouring LDS
+            // pointer, as the compiler does, the second buffer's entries fall outside the 8-bit offset fields of the LDS
+            // instructions and every odd pivot pays four address additions)
+            typedef __attribute__((address_space(3))) double LdsDouble; // 32-bit LDS addresses: one register each
+            LdsDouble *rtk = (LdsDouble *)(raw + tk), *rti = (LdsDouble *)(raw + ti);
+            asm volatile("" : "+v"(rtk), "+v"(rti));
 #pragma unroll
             for (int a0 = 0; a0 < NT; ++a0) {
                 const int jt_end = __builtin_amdgcn_readfirstlane(min(16, d - 16 * a0)); // one scalar loop bound, not a range test per pivot
@@ -640,9 +646,9 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
                                     part[j] = val; // the pivot, for the square roots after the loop (by its owner: a store of
                                                    // thread 0's own cost every wave a masked block per pivot)
                                 }
-                                row[16 * bb + tk] = (tk > jt) ? val : 0.0;
+                                rtk[par * RS + 16 * bb] = (tk > jt) ? val : 0.0;
                             } else {
-                                row[16 * bb + tk] = val;
+                                rtk[par * RS + 16 * bb] = val;
                             }
                         }
                     }
@@ -656,8 +662,8 @@ __global__ __launch_bounds__(kBlockThreads, NT <= 2 ? 4 : (NT <= 4 ? 3 : 2)) voi
                     double ri[NT], rk[NT];
 #pragma unroll
                     for (int x = a0; x < NT; ++x) {
-                        ri[x] = row[16 * x + ti];
-                        rk[x] = row[16 * x + tk];
+                        ri[x] = rti[par * RS + 16 * x];
+                        rk[x] = rtk[par * RS + 16 * x];
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     const double inv = fm_rcp(ajj);
